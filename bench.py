@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — candidate-poses/s of the PICCOLO pose refinement on MI355X (BASELINE.json metric).
+
+One STEP = the complete gradient-descent refinement of ONE query panorama: B candidate starting poses, num_iter = 100
+iterations (configs/stanford_parallel.ini shape: lr 0.1, patience 5, factor 0.8), each iteration one fused
+projection + bilinear sampling + loss + gradient pass over the whole cloud and one on-device optimiser epilogue.
+candidate-poses/s = B * images / wall time.  Inputs (packed cloud, packed panoramas, starting poses) are resident in
+HBM before the timed region starts.  Independent query images are sharded round-robin over the ranks (weak scaling:
+every rank refines `steps` images); the only collective is the final all_gather of the results (RCCL).
+
+    python bench.py                                   # 1 GPU, cfg2 (1M points, 2048x1024, 32 candidates)
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from piccolo_amd import _lib, ops, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (N points, H, W, B candidates, batch_mode)
+    "cfg1": (100_000, 256, 512, 1, False),
+    "cfg2": (1_000_000, 1024, 2048, 32, True),
+    "cfg3": (1_000_000, 1024, 2048, 256, True),
+    "cfg5": (10_000_000, 2048, 4096, 32, True),
+}
+NUM_ITER, LR, PATIENCE, FACTOR, QUANTILE = 100, 0.1, 5, 0.8, 0.05
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_POINT_POSE = 24      # xyz + rgb fp32 read once per pose evaluation
+
+
+def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=15.0):
+    """The oracle (C restatement of the reference's loss + gradient, OpenMP on all host cores) timed on a bounded
+    sample of the same workload: as many pose evaluations as fit in ~budget_s, scaled to candidate-poses/s."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = orc.max_threads()
+    t0 = time.perf_counter()
+    orc.sampling_loss(xyz, rgb, img, trans[:1], rot[:1], dtype=np.float32, grad=True)      # warm-up, also sizes the sample
+    t1 = time.perf_counter() - t0
+    n_pose = int(max(1, min(len(trans), budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    orc.sampling_loss(xyz, rgb, img, trans[:n_pose], rot[:n_pose], dtype=np.float32, grad=True)
+    dt = time.perf_counter() - t0
+    pose_evals_per_s = n_pose / dt
+    return {"value": pose_evals_per_s / NUM_ITER, "unit": "candidate-poses/s", "cores": cores, "kind": "port",
+            "sample": "%d fused loss+gradient pose evaluations over the full %d-point cloud (%.1f s), fp32 oracle/pcl_oracle.c "
+                      "with OpenMP; one candidate = %d evaluations" % (n_pose, len(xyz), dt, NUM_ITER),
+            "pose_evals_per_s": pose_evals_per_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
+                    help="per-launch HBM bytes from the rocprofv3 PMC passes (written by profiles/collect.sh)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)     # RCCL
+    _lib.load()
+
+    N, H, W, B, batch_mode = WORKLOADS[args.workload]
+    K, Wm = args.steps, args.warmup
+    n_img = K + Wm
+
+    # ---- untimed setup: synthetic room, one panorama per query image, everything packed and resident in HBM
+    xyz, rgb = synth.box_room(N, seed=0)                      # the shared cloud, replicated on every rank
+    X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+    cloud = ops.Cloud(X, C)
+    box = ops.quantile_box(X, QUANTILE)
+    panos, starts, gts = [], [], []
+    for i in range(n_img):
+        image_id = rank + i * world                           # round-robin sharding of the query images
+        t_gt, ypr_gt = synth.gt_pose(image_id)
+        cam = ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
+        img = torch.floor(ops.make_pano(cam, C, (H, W))) / 255.0      # uint8-quantised like a decoded image file
+        panos.append(ops.Pano(img))
+        tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=image_id)
+        starts.append((torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev)))
+        gts.append((t_gt, ypr_gt))
+        if i == 0 and rank == 0:
+            img0_host, start0_host = img.cpu().numpy(), (tr, ro)
+        del cam, img
+    results = torch.zeros(n_img, 16, device=dev)
+    timer = ops.KernelTimer(NUM_ITER * K)
+
+    def refine(i, tm=None):
+        gd = ops.GradientDescent(cloud, panos[i], starts[i][0], starts[i][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
+                                 batch_mode=batch_mode)
+        gd.run(NUM_ITER, timer=tm)
+        res = gd.result()
+        k = torch.argmin(res[:, 12])                           # winner = smallest loss of the last forward
+        results[i, :6] = res[k, :6]
+        results[i, 6] = res[k, 12]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(Wm):
+        refine(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Wm, n_img):
+        refine(i, timer)
+    if dist is not None:                                       # the path's only collective: gather the results
+        gathered = torch.empty(world * n_img, 16, device=dev)
+        dist.all_gather_into_tensor(gathered, results)
+    else:
+        gathered = results
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms, launches = timer.read()
+    # accuracy of this rank's images (localize.py:239-247 formulas)
+    errs = []
+    res_host = results.cpu().numpy()
+    for i in range(Wm, n_img):
+        R = ops.rot_from_ypr(torch.from_numpy(res_host[i, 3:6]))[0].cpu().numpy()
+        errs.append(synth.pose_errors(res_host[i, :3], R, gts[i][0], synth.rot_from_ypr_np(gts[i][1])))
+    errs = np.array(errs)
+
+    if rank == 0:
+        value = B * K * world / elapsed
+        per_launch_ms = kernel_ms / max(launches, 1)
+        alg_bytes = BYTES_PER_POINT_POSE * N * B
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                traffic = json.load(open(args.traffic_json)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "candidate-poses/s", "value": value, "unit": "candidate-poses/s", "n_gpus": world, "steps": K,
+            "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD iterations per query image"
+                                   % (args.workload, N, W, H, B, NUM_ITER),
+                       "images_per_gpu": K, "sharding": "query images round-robin over ranks, RCCL all_gather of results",
+                       "mode": "omniloc_batch" if batch_mode else "omniloc"},
+            "pose_evals_per_s": value * NUM_ITER,
+            "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
+            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<4,true,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches_timed": launches},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(xyz, rgb, img0_host, start0_host[0], start0_host[1])
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

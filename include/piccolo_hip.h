@@ -1,0 +1,148 @@
+/* piccolo_hip.h — C ABI of the MI355X (gfx950) implementation of PICCOLO's sampling-loss hot path.
+ *
+ * The reference (82magnolia/piccolo) is pure Python/PyTorch and has no FFI layer; its boundary for this path is
+ * the Python surface omniloc.py / utils.py.  This header is what a ctypes binding of that surface calls
+ * (see INTEGRATION.md for the stub).  Each entry point cites the reference code it replaces
+ * (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host; all buffers are caller-owned, the library
+ *    never allocates, frees or synchronises (graph-capture safe); `stream` is a hipStream_t passed as void*;
+ *  - every function returns 0 on success, a hipError_t value (> 0) for a runtime failure, or one of the
+ *    negative PCL_E* codes below for a bad argument;
+ *  - fp32 throughout, like the reference (localize.py:159-170); poses are (t[3], yaw, pitch, roll) with
+ *    p = R (x - t), R = RZ(yaw) RY(pitch) RX(roll)  (utils.py:425-453).
+ */
+#ifndef PICCOLO_HIP_H
+#define PICCOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCL_ABI_VERSION 1
+
+#define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
+#define PCL_EWORKSPACE (-2) /* workspace too small */
+
+/* number of floats per pose in result blocks: loss, count, dL/dt[3], dL/dyaw, dL/dpitch, dL/droll */
+#define PCL_RESULT_STRIDE 8
+
+int pcl_abi_version(void);
+const char *pcl_error_string(int code);
+
+/* ---- data layout in HBM ------------------------------------------------------------------------------------
+ * cloud : 6 planes (x, y, z, r, g, b) of pcl_cloud_stride(n) floats each — SoA so that a wavefront's 64 lanes
+ *         read 256 contiguous bytes per plane.  Built once per point cloud from the reference's row-major
+ *         (N,3) xyz and rgb tensors (localize.py:159-164).  `order` (nullable, int64[n]) gathers
+ *         point order[i] into slot i: passing a space-filling-curve order makes consecutive lanes hit
+ *         neighbouring texels (the loss is a sum over points, so the order does not change the result beyond
+ *         fp32 summation rounding).
+ * pano  : the query image (H,W,3) float (localize.py:167-170) repacked as (H+2, W+2) RGBA float4 texels with a
+ *         one-texel zero border, so grid_sample's zero padding (utils.py:98) needs no bounds test and one
+ *         bilinear tap is one 16-byte load.
+ */
+int64_t pcl_cloud_stride(int64_t n);
+size_t pcl_cloud_bytes(int64_t n);
+int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
+/* 63-bit Morton keys of xyz quantised to 21 bits per axis inside [lo, hi] (host arrays of 3); sort them to get `order`. */
+int pcl_morton_keys(const float *xyz, int64_t n, const float *lo_host, const float *hi_host, int64_t *keys, void *stream);
+
+size_t pcl_pano_bytes(int H, int W);
+int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream);
+
+/* ---- sampling loss (+ gradient) ----------------------------------------------------------------------------
+ * Replaces SamplingLoss.forward (omniloc.py:171-202), BatchSamplingLoss.forward (omniloc.py:311-356), the forward
+ * in trim_input_loss (utils.py:484-499) and sampling_loss (omniloc.py:105-157), plus — with with_grad != 0 — the
+ * autograd backward the reference runs at omniloc.py:47,254, all fused in one pass over the cloud.
+ *
+ *   trans [B][3], rot [B][3] = (yaw, pitch, roll)
+ *   result[B][PCL_RESULT_STRIDE] = loss, count, dL/dt(3), dL/d(yaw,pitch,roll)   (grad slots 0 if !with_grad)
+ *   visible : nullable uint8 [B][n] in PACKED point order, multiplied into the mask (build-defined depth mask,
+ *             off in the reference; see pcl_scatter_min_depth)
+ * loss = sum_i mask_i ||c_i - rgb_i||_2 / sum_i mask_i, mask_i = sampled colour not exactly (0,0,0); 0/0 -> NaN.
+ */
+size_t pcl_loss_workspace_bytes(int64_t n, int B);
+int pcl_sampling_loss(const float *cloud, int64_t n, const float *pano, int H, int W, const float *trans,
+                      const float *rot, int B, int with_grad, const uint8_t *visible, float *result, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* ---- gradient-descent refinement ---------------------------------------------------------------------------
+ * Replaces the optimisation loops of omniloc (omniloc.py:44-58) and omniloc_batch (omniloc.py:249-269): per
+ * iteration one fused loss+gradient pass and one epilogue that does, per candidate and entirely on the device,
+ * the final reduction, the chain rule to (t, yaw, pitch, roll), torch.optim.Adam (betas 0.9/0.999, eps 1e-8),
+ * ReduceLROnPlateau(mode='min', threshold 1e-4 rel, cooldown 0, min_lr 0, eps 1e-8) and the clamp of t to `box`.
+ *
+ *   mode PCL_GD_SEQUENTIAL : clamp applies to the parameters the next forward sees          (omniloc.py:52-58)
+ *   mode PCL_GD_BATCH      : the next forward sees the post-step PRE-clamp copy while Adam keeps updating the
+ *                            clamped leaf (one-iteration lag of omniloc.py:260-269)
+ *   box[6] = x_min, x_max, y_min, y_max, z_min, z_max  (device; quantile() of each xyz column, omniloc.py:53-55)
+ *   state   : pcl_gd_state_bytes(B) bytes, opaque; pcl_gd_init fills it from the starting poses
+ *   loss_history : nullable [num_iter][B]; loss of every forward
+ * pcl_gd_run enqueues num_iter iterations back to back (no host synchronisation; capturable in a hipGraph) and may
+ * be called repeatedly to continue.  pcl_gd_result writes, per candidate, PCL_GD_RESULT_STRIDE floats:
+ *   fwd t(3), fwd ypr(3)  — the pose the reference returns (omniloc.py:102 / :272-275),
+ *   leaf t(3), leaf ypr(3) — what the caller's input_trans/input_rot rows hold afterwards (omniloc.py:15-19,216-219),
+ *   last loss (loss of the LAST forward, i.e. at the pose before the final update, omniloc.py:46,102,271,276), lr.
+ */
+#define PCL_GD_SEQUENTIAL 0
+#define PCL_GD_BATCH 1
+#define PCL_GD_RESULT_STRIDE 14
+
+typedef struct pcl_gd_hyper {
+    double lr;        /* cfg.lr        (omniloc.py:25)  */
+    double factor;    /* cfg.factor    (omniloc.py:28)  */
+    int32_t patience; /* cfg.patience  (omniloc.py:27)  */
+    int32_t mode;     /* PCL_GD_SEQUENTIAL | PCL_GD_BATCH */
+} pcl_gd_hyper;
+
+size_t pcl_gd_state_bytes(int B);
+int pcl_gd_init(void *state, const float *trans, const float *rot, int B, const pcl_gd_hyper *hyper_host, void *stream);
+int pcl_gd_run(const float *cloud, int64_t n, const float *pano, int H, int W, void *state, int B, const float *box,
+               const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
+               size_t workspace_bytes, void *timer, void *stream);
+int pcl_gd_result(const void *state, int B, float *result, void *stream);
+
+/* ---- kernel timer (measurement aid, HOST object) --------------------------------------------------------------
+ * A pool of hipEvent pairs.  When a timer is passed to pcl_gd_run, every launch of the fused loss+gradient kernel is
+ * bracketed by an event pair recorded on `stream` (no synchronisation inside the run).  pcl_timer_read synchronises
+ * on the recorded events and returns the summed kernel time and the number of launches since the last reset.
+ * Launches beyond `capacity` are simply not timed. */
+void *pcl_timer_create(int capacity);
+void pcl_timer_destroy(void *timer);
+void pcl_timer_reset(void *timer);
+int pcl_timer_read(void *timer, double *total_ms_host, int *launches_host);
+
+/* ---- stand-alone ops of the path ---------------------------------------------------------------------------- */
+/* utils.py:16-61 cloud2idx: xyz [n][3] -> coord [n][2] in [-1,1]^2 (batched form = same call on B*n points). */
+int pcl_cloud2idx(const float *xyz, int64_t n, float *coord, void *stream);
+/* utils.py:64-103 sample_from_img: clip to +-0.99, bilinear, zero padding, align_corners=False; rgb_out [n][3]. */
+int pcl_sample_from_img(const float *pano, int H, int W, const float *coord, int64_t n, float *rgb_out, void *stream);
+/* utils.py:425-453 rot_from_ypr for B poses: rot [B][3] -> R [B][9] row-major. */
+int pcl_rot_from_ypr(const float *rot, int B, float *R, void *stream);
+/* utils.py:208-229 quantile on each of the 3 columns of xyz [n][3]: box[6] = x[int(n q)], x[int(n (1-q))], y.., z..
+ * (exact order statistics by radix select; workspace pcl_quantile_workspace_bytes()). */
+size_t pcl_quantile_workspace_bytes(void);
+int pcl_quantile_box(const float *xyz, int64_t n, double q, float *box, void *workspace, void *stream);
+
+/* Build-defined scatter-min visibility (the reference imports torch_scatter.scatter_min at utils.py:6 but never
+ * calls it).  For camera-frame points xyz_cam [n][3]: pixel = make_pano's (utils.py:158-165), depth = ||p||
+ * (utils.py:152); zbuf [H*W] uint64 = min over the pixel of (depth_bits << 32 | index), 0xFFFF... if empty.
+ * pcl_scatter_min_unpack turns it into torch_scatter's (out, arg) convention: empty -> (0, n). */
+int pcl_scatter_min_depth(const float *xyz_cam, int64_t n, int H, int W, uint64_t *zbuf, void *stream);
+int pcl_scatter_min_unpack(const uint64_t *zbuf, int64_t n, int H, int W, float *zmin, int64_t *argmin, void *stream);
+/* utils.py:134-205 make_pano: 3x3 splat, nearest point wins inside a pass, later passes overwrite earlier ones
+ * (order idx8..idx1, centre; utils.py:190-198).  image [H][W][3] float = rgb*255 (0 where nothing projects).
+ * workspace: H*W uint64. */
+int pcl_make_pano(const float *xyz_cam, const float *rgb, int64_t n, int H, int W, float *image, uint64_t *workspace,
+                  void *stream);
+/* p = R (x - t) for one pose: xyz [n][3] -> out [n][3] (feeds make_pano / scatter-min; localize.py:266-267). */
+int pcl_transform_cloud(const float *xyz, int64_t n, const float *trans, const float *rot, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICCOLO_HIP_H */

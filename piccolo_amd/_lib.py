@@ -1,0 +1,88 @@
+"""ctypes binding of include/piccolo_hip.h (the product's only compute back end).
+
+There is deliberately NO fallback: if libpiccolo_hip.so is missing or has the wrong ABI, importing the
+product's ops raises.  Build it with `python -m piccolo_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_c = ctypes
+_vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
+
+ABI_VERSION = 1
+RESULT_STRIDE = 8
+GD_RESULT_STRIDE = 14
+GD_SEQUENTIAL, GD_BATCH = 0, 1
+
+
+class GdHyper(_c.Structure):
+    _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/piccolo_hip.h declares
+SIGNATURES = {
+    "pcl_abi_version": (_int, []),
+    "pcl_error_string": (_c.c_char_p, [_int]),
+    "pcl_cloud_stride": (_i64, [_i64]),
+    "pcl_cloud_bytes": (_sz, [_i64]),
+    "pcl_cloud_pack": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "pcl_morton_keys": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _vp, _vp]),
+    "pcl_pano_bytes": (_sz, [_int, _int]),
+    "pcl_pano_pack": (_int, [_vp, _int, _int, _vp, _vp]),
+    "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
+    "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_gd_state_bytes": (_sz, [_int]),
+    "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),
+    "pcl_gd_run": (_int, [_vp, _i64, _vp, _int, _int, _vp, _int, _vp, _c.POINTER(GdHyper), _int, _vp, _vp, _sz, _vp, _vp]),
+    "pcl_timer_create": (_vp, [_int]),
+    "pcl_timer_destroy": (None, [_vp]),
+    "pcl_timer_reset": (None, [_vp]),
+    "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
+    "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
+    "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),
+    "pcl_sample_from_img": (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp]),
+    "pcl_rot_from_ypr": (_int, [_vp, _int, _vp, _vp]),
+    "pcl_quantile_workspace_bytes": (_sz, []),
+    "pcl_quantile_box": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp]),
+    "pcl_scatter_min_depth": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
+    "pcl_scatter_min_unpack": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
+    "pcl_make_pano": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
+    "pcl_transform_cloud": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class PiccoloHipError(RuntimeError):
+    pass
+
+
+def so_path():
+    return _build.SO
+
+
+def load():
+    """Load libpiccolo_hip.so (never builds implicitly on the hot path; raises if absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = so_path()
+    if not os.path.exists(path):
+        raise PiccoloHipError(
+            "piccolo_amd: %s not found. The MI355X HIP library is the only back end (no CPU fallback); "
+            "build it with `python -m piccolo_amd.build`." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.pcl_abi_version() != ABI_VERSION:
+        raise PiccoloHipError("piccolo_amd: ABI mismatch: library %d, binding %d" % (lib.pcl_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PiccoloHipError("%s failed: %s (code %d)" % (what, load().pcl_error_string(rc).decode(), rc))

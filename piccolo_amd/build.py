@@ -1,0 +1,50 @@
+"""Builds piccolo_amd/lib/libpiccolo_hip.so from piccolo_amd/csrc/*.hip with hipcc for gfx950.
+
+In-tree on purpose: the .so is git-ignored but travels with the working tree (gpurun snapshot), and the product
+refuses to run without it (piccolo_amd/_lib.py) — there is no CPU fallback.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+SO = os.path.join(OUT_DIR, "libpiccolo_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "piccolo_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not stale():
+        return SO
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+           "-Wall", "-Wno-unused-function", "-o", SO] + list(extra_flags) + sources()
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

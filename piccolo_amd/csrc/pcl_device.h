@@ -1,0 +1,129 @@
+// pcl_device.h — device-side building blocks shared by the gfx950 kernels of the PICCOLO sampling-loss path.
+// Wavefront = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/piccolo_hip.h"
+
+#define PCL_WAVE 64
+#define PCL_BLOCK 256
+#define PCL_NACC 8  // per-pose accumulators: sum ||d||, count, sum g (3), sum p x g (3)
+
+typedef float pcl_f4 __attribute__((ext_vector_type(4)));
+typedef int pcl_i4 __attribute__((ext_vector_type(4)));
+
+// One candidate pose as the loss kernel consumes it (scalar loads): p = R (x - t).
+struct PclPoseRec {
+    float R[9];
+    float t[3];
+    float pad[4];
+};
+static_assert(sizeof(PclPoseRec) == 64, "pose record is one 64-byte scalar-load line");
+
+// Per-candidate optimiser state of the on-device GD loop (pcl_gd.hip).
+struct PclGdPose {
+    double lr;    // this candidate's Adam learning rate (python float in the reference)
+    double best;  // ReduceLROnPlateau.best
+    float leaf[6];  // Adam's parameters: t(3), yaw, pitch, roll
+    float fwd[6];   // parameters the next forward sees (== leaf in sequential mode; pre-clamp copy in batch mode)
+    float m[6];     // exp_avg
+    float v[6];     // exp_avg_sq
+    float last_loss;
+    int32_t num_bad;
+    int32_t step;
+    int32_t pad;
+};
+static_assert(sizeof(PclGdPose) == 128, "GD state record");
+
+struct PclDims {
+    int H, W;    // panorama size
+    int Wp;      // padded row length in texels (W + 2)
+    float half_w, half_h;    // W/2, H/2            (grid_sample unnormalise)
+    float off_x, off_y;      // (W-1)/2 + 1, (H-1)/2 + 1 : pixel coordinate in the zero-bordered texture
+    float k_phi, k_theta;    // -W/(2 pi), H/pi     (d ix / d phi, d iy / d theta)
+};
+
+__host__ __device__ inline PclDims pcl_make_dims(int H, int W)
+{
+    PclDims d;
+    d.H = H; d.W = W; d.Wp = W + 2;
+    d.half_w = 0.5f * (float)W; d.half_h = 0.5f * (float)H;
+    d.off_x = 0.5f * (float)(W - 1) + 1.0f; d.off_y = 0.5f * (float)(H - 1) + 1.0f;
+    d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846));
+    d.k_theta = (float)((double)H / 3.14159265358979323846);
+    return d;
+}
+
+// R = RZ(yaw) RY(pitch) RX(roll) (reference utils.py:425-453). sin/cos are evaluated in double and rounded once,
+// which lands within an ulp of the fp32 values ATen computes on the host.
+__device__ inline void pcl_rot_from_ypr(float yaw, float pitch, float roll, float R[9])
+{
+    double sy, cy, sp, cp, sr, cr;
+    sincos((double)yaw, &sy, &cy);
+    sincos((double)pitch, &sp, &cp);
+    sincos((double)roll, &sr, &cr);
+    sy = (double)(float)sy; cy = (double)(float)cy; sp = (double)(float)sp;
+    cp = (double)(float)cp; sr = (double)(float)sr; cr = (double)(float)cr;
+    // RZ RY = [[cy cp, -sy, cy sp], [sy cp, cy, sy sp], [-sp, 0, cp]]
+    R[0] = (float)(cy * cp); R[1] = (float)(cy * sp * sr - sy * cr); R[2] = (float)(cy * sp * cr + sy * sr);
+    R[3] = (float)(sy * cp); R[4] = (float)(sy * sp * sr + cy * cr); R[5] = (float)(sy * sp * cr - cy * sr);
+    R[6] = (float)(-sp);     R[7] = (float)(cp * sr);                R[8] = (float)(cp * cr);
+}
+
+__device__ inline void pcl_write_pose_rec(PclPoseRec* rec, const float p[6])
+{
+    float R[9];
+    pcl_rot_from_ypr(p[3], p[4], p[5], R);
+    for (int k = 0; k < 9; k++) rec->R[k] = R[k];
+    rec->t[0] = p[0]; rec->t[1] = p[1]; rec->t[2] = p[2];
+    rec->pad[0] = rec->pad[1] = rec->pad[2] = rec->pad[3] = 0.f;
+}
+
+// Equirectangular projection of a camera-frame point (reference utils.py:44-59):
+//   theta = atan2(|p_xy|, p_z + 1e-6), phi = atan2(p_y, p_x + 1e-6) + pi, g = (1 - phi/pi, 2 theta/pi - 1)
+// written with the same operation order as the reference so the stand-alone op matches it to an ulp or two.
+__device__ inline void pcl_cloud2idx_point(float px, float py, float pz, float& gx, float& gy)
+{
+    const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
+    float rho = sqrtf(px * px + py * py);
+    float theta = atan2f(rho, pz + 1e-6f);
+    float phi = atan2f(py, px + 1e-6f) + pi;
+    float cx = 1.0f - phi / two_pi;
+    float cy = theta / pi;
+    gx = 2.0f * cx - 1.0f;
+    gy = 2.0f * cy - 1.0f;
+}
+
+__device__ inline __amdgpu_buffer_rsrc_t pcl_tex_rsrc(const float* pano, int H, int W)
+{
+    // raw buffer, 32-bit offsets, bounds-checked by hardware against the padded texture size
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pano, 0, (int)((size_t)(H + 2) * (size_t)(W + 2) * 16u), 0x00020000);
+}
+
+__device__ inline pcl_f4 pcl_texel(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
+{
+    pcl_i4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return __builtin_bit_cast(pcl_f4, v);
+}
+
+__device__ inline float pcl_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ inline double pcl_wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// hipError_t passthrough for launch wrappers
+#define PCL_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e_ = hipGetLastError();         \
+        if (e_ != hipSuccess) return (int)e_;      \
+    } while (0)

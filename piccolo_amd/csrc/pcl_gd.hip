@@ -1,0 +1,284 @@
+// pcl_gd.hip — second-stage reduction, chain rule to (t, yaw, pitch, roll) and the on-device optimiser epilogue.
+//
+// Replaces, per GD iteration of the reference: the tail of autograd (omniloc.py:47,254), B x Adam.step and
+// B x ReduceLROnPlateau.step(float(loss)) — each a host sync — (omniloc.py:49-50, :256-258), the re-cat of the
+// parameters (omniloc.py:260-263) and the clamp to the quantile box (omniloc.py:52-58, :265-269).
+// One 64-lane block per candidate pose; lane 0 runs the scalar optimiser update in the same precision mix as
+// the reference (fp32 tensors, python-double scalars).
+#include "pcl_device.h"
+
+int pcl_launch_loss(const float* cloud, int64_t n, const float* pano, int H, int W, const PclPoseRec* poses, int B,
+                    bool grad, const uint8_t* visible, float* partials, hipStream_t s);
+size_t pcl_partials_bytes(int64_t n, int B);
+int pcl_plan_nchunks(int64_t n, int B);
+
+// Deterministic second-stage sum of the per-chunk partials of pose `b` (fixed lane->chunk assignment, double).
+__device__ inline void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, double out[PCL_NACC])
+{
+    double s[PCL_NACC];
+#pragma unroll
+    for (int k = 0; k < PCL_NACC; k++) s[k] = 0.0;
+    for (int c = threadIdx.x; c < nchunks; c += PCL_WAVE) {
+        const pcl_f4* p = reinterpret_cast<const pcl_f4*>(partials + ((int64_t)c * B + b) * PCL_NACC);
+        pcl_f4 lo = p[0], hi = p[1];
+        s[0] += lo.x; s[1] += lo.y; s[2] += lo.z; s[3] += lo.w;
+        s[4] += hi.x; s[5] += hi.y; s[6] += hi.z; s[7] += hi.w;
+    }
+#pragma unroll
+    for (int k = 0; k < PCL_NACC; k++) out[k] = pcl_wave_sum_d(s[k]);
+}
+
+// loss and gradient w.r.t. (t, yaw, pitch, roll) from the 8 sums, at pose p = (t, yaw, pitch, roll).
+//   dL/dt = -R^T sum g / M ;  dL/dyaw = e_z . T/M ; dL/dpitch = (RZ e_y) . T/M ; dL/droll = (RZ RY e_x) . T/M
+// with T = sum p x g (see pcl_loss.hip).  M = 0 gives NaN like the reference's 0/0.
+__device__ inline void pcl_chain_rule(const double s[PCL_NACC], const float R[9], const float p[6], float& loss, float grad[6])
+{
+    double M = s[1];
+    loss = (float)s[0] / (float)M;
+    double inv = 1.0 / M;
+    for (int k = 0; k < 3; k++) grad[k] = (float)(-((double)R[k] * s[2] + (double)R[3 + k] * s[3] + (double)R[6 + k] * s[4]) * inv);
+    double sy, cy, sp, cp;
+    sincos((double)p[3], &sy, &cy);
+    sincos((double)p[4], &sp, &cp);
+    grad[3] = (float)(s[7] * inv);
+    grad[4] = (float)((-sy * s[5] + cy * s[6]) * inv);
+    grad[5] = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
+}
+
+// ---------------------------------------------------------------- stateless loss: pose setup + finish
+
+__global__ void pcl_pose_setup_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int B, PclPoseRec* recs)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float p[6] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2], rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
+    pcl_write_pose_rec(&recs[b], p);
+}
+
+__global__ void __launch_bounds__(PCL_WAVE) pcl_finish_kernel(const float* __restrict__ partials, int nchunks, int B,
+                                                              const PclPoseRec* __restrict__ recs,
+                                                              const float* __restrict__ rot, int with_grad,
+                                                              float* __restrict__ result)
+{
+    int b = blockIdx.x;
+    double s[PCL_NACC];
+    pcl_reduce_partials(partials, nchunks, B, b, s);
+    if (threadIdx.x == 0) {
+        float p[6] = {0, 0, 0, rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
+        float loss, g[6] = {0, 0, 0, 0, 0, 0};
+        if (with_grad) pcl_chain_rule(s, recs[b].R, p, loss, g);
+        else loss = (float)s[0] / (float)s[1];
+        float* r = result + (int64_t)b * PCL_RESULT_STRIDE;
+        r[0] = loss; r[1] = (float)s[1];
+        for (int k = 0; k < 6; k++) r[2 + k] = g[k];
+    }
+}
+
+extern "C" size_t pcl_loss_workspace_bytes(int64_t n, int B)
+{
+    if (n <= 0 || B <= 0) return 0;
+    return (size_t)B * sizeof(PclPoseRec) + pcl_partials_bytes(n, B);
+}
+
+extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const float* pano, int H, int W, const float* trans,
+                                 const float* rot, int B, int with_grad, const uint8_t* visible, float* result,
+                                 void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !pano || !trans || !rot || !result || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (workspace_bytes < pcl_loss_workspace_bytes(n, B)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    PclPoseRec* recs = (PclPoseRec*)workspace;
+    float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
+    hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
+    PCL_LAUNCH_CHECK();
+    int rc = pcl_launch_loss(cloud, n, pano, H, W, recs, B, with_grad != 0, visible, partials, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
+                       with_grad, result);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------- GD: state init, epilogue, run, result
+
+// state blob = PclGdPose[B] followed by PclPoseRec[B]
+static inline PclGdPose* gd_poses(void* state) { return (PclGdPose*)state; }
+static inline PclPoseRec* gd_recs(void* state, int B) { return (PclPoseRec*)((char*)state + (size_t)B * sizeof(PclGdPose)); }
+
+__global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float* __restrict__ trans,
+                                   const float* __restrict__ rot, int B, double lr)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    PclGdPose g;
+    g.lr = lr;
+    g.best = __builtin_inf();   // ReduceLROnPlateau: mode_worse = +inf
+    for (int k = 0; k < 3; k++) { g.leaf[k] = trans[3 * b + k]; g.leaf[3 + k] = rot[3 * b + k]; }
+    for (int k = 0; k < 6; k++) { g.fwd[k] = g.leaf[k]; g.m[k] = 0.f; g.v[k] = 0.f; }
+    g.last_loss = 0.f; g.num_bad = 0; g.step = 0; g.pad = 0;
+    st[b] = g;
+    pcl_write_pose_rec(&recs[b], g.fwd);
+}
+
+__global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks, int B,
+                                                                   PclGdPose* st, PclPoseRec* recs,
+                                                                   const float* __restrict__ box, double factor,
+                                                                   int patience, int mode, float* loss_out)
+{
+    int b = blockIdx.x;
+    double s[PCL_NACC];
+    pcl_reduce_partials(partials, nchunks, B, b, s);
+    if (threadIdx.x != 0) return;
+    PclGdPose g = st[b];
+    float loss, grad[6];
+    pcl_chain_rule(s, recs[b].R, g.fwd, loss, grad);
+    g.last_loss = loss;
+    if (loss_out) loss_out[b] = loss;
+
+    // torch.optim.Adam, single-tensor form (betas 0.9/0.999, eps 1e-8; call sites omniloc.py:33,235-236):
+    // fp32 tensor math, python-double scalars
+    const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+    g.step += 1;
+    double bc1 = 1.0 - pow(beta1, (double)g.step);
+    double bc2 = 1.0 - pow(beta2, (double)g.step);
+    float step_size = (float)(-(g.lr / bc1));
+    float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        float gk = grad[k];
+        g.m[k] = g.m[k] + w1 * (gk - g.m[k]);                 // exp_avg.lerp_(grad, 1 - beta1)
+        g.v[k] = g.v[k] * b2 + w2 * gk * gk;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        float denom = sqrtf(g.v[k]) / bc2_sqrt + (float)eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+        g.leaf[k] = g.leaf[k] + step_size * g.m[k] / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+
+    // ReduceLROnPlateau(mode='min', threshold=1e-4 rel, cooldown=0, min_lr=0, eps=1e-8).step(float(loss))
+    // (omniloc.py:37,50 / :237,258)
+    double cur = (double)loss;
+    if (cur < g.best * (1.0 - 1e-4)) { g.best = cur; g.num_bad = 0; }
+    else g.num_bad += 1;
+    if (g.num_bad > patience) {
+        double new_lr = g.lr * factor;
+        if (new_lr < 0.0) new_lr = 0.0;
+        if (g.lr - new_lr > 1e-8) g.lr = new_lr;
+        g.num_bad = 0;
+    }
+
+    // clamp t to the quantile box; batch mode forwards the pre-clamp copy (omniloc.py:260-269), sequential mode
+    // clamps the very tensor the next forward reads (omniloc.py:56-58)
+    if (mode == PCL_GD_BATCH)
+        for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    for (int k = 0; k < 3; k++) g.leaf[k] = fminf(fmaxf(g.leaf[k], box[2 * k]), box[2 * k + 1]);
+    if (mode != PCL_GD_BATCH)
+        for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    st[b] = g;
+    pcl_write_pose_rec(&recs[b], g.fwd);
+}
+
+__global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, float* __restrict__ result)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* r = result + (int64_t)b * PCL_GD_RESULT_STRIDE;
+    for (int k = 0; k < 6; k++) { r[k] = st[b].fwd[k]; r[6 + k] = st[b].leaf[k]; }
+    r[12] = st[b].last_loss;
+    r[13] = (float)st[b].lr;
+}
+
+extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? (size_t)B * (sizeof(PclGdPose) + sizeof(PclPoseRec)) : 0; }
+
+extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, int B, const pcl_gd_hyper* hyper_host, void* stream)
+{
+    if (!state || !trans || !rot || !hyper_host || B <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_gd_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_poses(state),
+                       gd_recs(state, B), trans, rot, B, hyper_host->lr);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- kernel timer: host-side pool of event pairs (include/piccolo_hip.h)
+struct PclTimer {
+    int capacity, used;
+    hipEvent_t* start;
+    hipEvent_t* stop;
+};
+
+extern "C" void* pcl_timer_create(int capacity)
+{
+    if (capacity <= 0) return nullptr;
+    PclTimer* t = new PclTimer;
+    t->capacity = capacity; t->used = 0;
+    t->start = new hipEvent_t[capacity];
+    t->stop = new hipEvent_t[capacity];
+    for (int i = 0; i < capacity; i++) {
+        if (hipEventCreate(&t->start[i]) != hipSuccess || hipEventCreate(&t->stop[i]) != hipSuccess) {
+            for (int j = 0; j <= i; j++) { (void)hipEventDestroy(t->start[j]); if (j < i) (void)hipEventDestroy(t->stop[j]); }
+            delete[] t->start; delete[] t->stop; delete t;
+            return nullptr;
+        }
+    }
+    return t;
+}
+
+extern "C" void pcl_timer_destroy(void* timer)
+{
+    PclTimer* t = (PclTimer*)timer;
+    if (!t) return;
+    for (int i = 0; i < t->capacity; i++) { (void)hipEventDestroy(t->start[i]); (void)hipEventDestroy(t->stop[i]); }
+    delete[] t->start; delete[] t->stop; delete t;
+}
+
+extern "C" void pcl_timer_reset(void* timer) { if (timer) ((PclTimer*)timer)->used = 0; }
+
+extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_host)
+{
+    PclTimer* t = (PclTimer*)timer;
+    if (!t || !total_ms_host || !launches_host) return PCL_EINVAL;
+    double total = 0.0;
+    for (int i = 0; i < t->used; i++) {
+        hipError_t e = hipEventSynchronize(t->stop[i]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, t->start[i], t->stop[i]);
+        if (e != hipSuccess) return (int)e;
+        total += (double)ms;
+    }
+    *total_ms_host = total; *launches_host = t->used;
+    return 0;
+}
+
+extern "C" int pcl_gd_run(const float* cloud, int64_t n, const float* pano, int H, int W, void* state, int B,
+                          const float* box, const pcl_gd_hyper* hyper_host, int num_iter, float* loss_history,
+                          void* workspace, size_t workspace_bytes, void* timer, void* stream)
+{
+    PclTimer* tm = (PclTimer*)timer;
+    if (!cloud || !pano || !state || !box || !hyper_host || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0 || num_iter < 0)
+        return PCL_EINVAL;
+    if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
+    if (workspace_bytes < pcl_partials_bytes(n, B)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partials = (float*)workspace;
+    const int nchunks = pcl_plan_nchunks(n, B);
+    for (int it = 0; it < num_iter; it++) {
+        const bool timed = tm && tm->used < tm->capacity;
+        if (timed) (void)hipEventRecord(tm->start[tm->used], s);
+        int rc = pcl_launch_loss(cloud, n, pano, H, W, gd_recs(state, B), B, true, nullptr, partials, s);
+        if (timed) (void)hipEventRecord(tm->stop[tm->used++], s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, nchunks, B, gd_poses(state),
+                           gd_recs(state, B), box, hyper_host->factor, (int)hyper_host->patience, (int)hyper_host->mode,
+                           loss_history ? loss_history + (int64_t)it * B : nullptr);
+        PCL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int pcl_gd_result(const void* state, int B, float* result, void* stream)
+{
+    if (!state || !result || B <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_gd_result_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const PclGdPose*)state, B, result);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}

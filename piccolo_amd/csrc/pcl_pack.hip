@@ -1,0 +1,107 @@
+// pcl_pack.hip — one-time repacking of the reference's tensors into the layouts the loss kernel streams.
+//   cloud : row-major (N,3) xyz + (N,3) rgb  (localize.py:159-164)  -> 6 SoA planes, optionally re-ordered
+//   pano  : (H,W,3) float image              (localize.py:167-170)  -> zero-bordered (H+2, W+2) RGBA float4
+#include "pcl_device.h"
+
+extern "C" int pcl_abi_version(void) { return PCL_ABI_VERSION; }
+
+extern "C" const char* pcl_error_string(int code)
+{
+    if (code == 0) return "success";
+    if (code == PCL_EINVAL) return "piccolo_hip: invalid argument";
+    if (code == PCL_EWORKSPACE) return "piccolo_hip: workspace too small";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "piccolo_hip: unknown error";
+}
+
+// plane stride: n rounded up to 256 floats (1 KiB) so every plane starts on a fresh 1-KiB wave-load boundary
+extern "C" int64_t pcl_cloud_stride(int64_t n) { return n <= 0 ? 0 : ((n + 255) / 256) * 256; }
+extern "C" size_t pcl_cloud_bytes(int64_t n) { return (size_t)pcl_cloud_stride(n) * 6 * sizeof(float); }
+extern "C" size_t pcl_pano_bytes(int H, int W) { return (H <= 0 || W <= 0) ? 0 : (size_t)(H + 2) * (size_t)(W + 2) * 16; }
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_cloud_pack_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                                                   const int64_t* __restrict__ order, int64_t n,
+                                                                   int64_t stride, float* __restrict__ cloud)
+{
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= stride) return;
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int64_t j = order ? order[i] : i;
+        v[0] = xyz[3 * j]; v[1] = xyz[3 * j + 1]; v[2] = xyz[3 * j + 2];
+        v[3] = rgb[3 * j]; v[4] = rgb[3 * j + 1]; v[5] = rgb[3 * j + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) cloud[k * stride + i] = v[k];
+}
+
+extern "C" int pcl_cloud_pack(const float* xyz, const float* rgb, const int64_t* order, int64_t n, float* cloud, void* stream)
+{
+    if (!xyz || !rgb || !cloud || n <= 0) return PCL_EINVAL;
+    int64_t stride = pcl_cloud_stride(n);
+    hipLaunchKernelGGL(pcl_cloud_pack_kernel, dim3((unsigned)(stride / PCL_BLOCK)), dim3(PCL_BLOCK), 0, (hipStream_t)stream,
+                       xyz, rgb, order, n, stride, cloud);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ inline uint64_t pcl_spread21(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_morton_kernel(const float* __restrict__ xyz, int64_t n, float lx, float ly,
+                                                               float lz, float sx, float sy, float sz,
+                                                               int64_t* __restrict__ keys)
+{
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float top = 2097151.f;  // 2^21 - 1
+    float fx = __builtin_amdgcn_fmed3f((xyz[3 * i] - lx) * sx, 0.f, top);
+    float fy = __builtin_amdgcn_fmed3f((xyz[3 * i + 1] - ly) * sy, 0.f, top);
+    float fz = __builtin_amdgcn_fmed3f((xyz[3 * i + 2] - lz) * sz, 0.f, top);
+    uint64_t k = pcl_spread21((uint32_t)fx) | (pcl_spread21((uint32_t)fy) << 1) | (pcl_spread21((uint32_t)fz) << 2);
+    keys[i] = (int64_t)k;
+}
+
+extern "C" int pcl_morton_keys(const float* xyz, int64_t n, const float* lo, const float* hi, int64_t* keys, void* stream)
+{
+    if (!xyz || !lo || !hi || !keys || n <= 0) return PCL_EINVAL;
+    float s[3];
+    for (int k = 0; k < 3; k++) s[k] = hi[k] > lo[k] ? 2097151.f / (hi[k] - lo[k]) : 0.f;
+    hipLaunchKernelGGL(pcl_morton_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, xyz, n, lo[0], lo[1], lo[2], s[0], s[1], s[2], keys);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_kernel(const float* __restrict__ img, int H, int W,
+                                                                  pcl_f4* __restrict__ pano)
+{
+    int Wp = W + 2, Hp = H + 2;
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= (int64_t)Wp * Hp) return;
+    int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+    pcl_f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+        const float* s = img + ((int64_t)(yp - 1) * W + (xp - 1)) * 3;
+        v.x = s[0]; v.y = s[1]; v.z = s[2];
+    }
+    pano[i] = v;
+}
+
+extern "C" int pcl_pano_pack(const float* img_hwc, int H, int W, float* pano, void* stream)
+{
+    if (!img_hwc || !pano || H <= 0 || W <= 0) return PCL_EINVAL;
+    int64_t total = (int64_t)(H + 2) * (W + 2);
+    hipLaunchKernelGGL(pcl_pano_pack_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, img_hwc, H, W, (pcl_f4*)pano);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}

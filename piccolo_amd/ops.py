@@ -1,0 +1,232 @@
+"""Torch-tensor front end of the C ABI: device memory and streams come from PyTorch-ROCm (plumbing), every
+computation is a HIP kernel in libpiccolo_hip.so.
+
+Inputs may live on the CPU (the reference's harness hands over whatever `device` it picked, localize.py:124):
+they are uploaded to cuda:0.  Without a GPU or without the library every call raises — there is no fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def device():
+    if not torch.cuda.is_available():
+        raise _lib.PiccoloHipError("piccolo_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dev(t, dtype=F32):
+    """contiguous tensor of `dtype` on the GPU (detached)."""
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(t)
+    return t.detach().to(device=device(), dtype=dtype).contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bytes(nbytes):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device())
+
+
+class Cloud:
+    """Point cloud packed for the loss kernel: 6 SoA planes, by default in Morton order of xyz.
+
+    `order` maps packed slot -> original point index (None if the original order was kept)."""
+
+    def __init__(self, xyz, rgb, sort=True):
+        lib = _lib.load()
+        xyz, rgb = _dev(xyz), _dev(rgb)
+        if xyz.dim() != 2 or xyz.shape[1] != 3 or rgb.shape != xyz.shape:
+            raise ValueError("xyz and rgb must both be (N, 3)")
+        self.n = int(xyz.shape[0])
+        if self.n <= 0:
+            raise ValueError("empty point cloud")
+        self.order = None
+        if sort and self.n > 1:
+            lo = xyz.min(0).values.cpu()
+            hi = xyz.max(0).values.cpu()
+            keys = torch.empty(self.n, dtype=torch.int64, device=xyz.device)
+            lo_c = (ctypes.c_float * 3)(*[float(v) for v in lo])
+            hi_c = (ctypes.c_float * 3)(*[float(v) for v in hi])
+            _lib.check(lib.pcl_morton_keys(_ptr(xyz), self.n, lo_c, hi_c, _ptr(keys), _stream()), "pcl_morton_keys")
+            self.order = torch.argsort(keys)   # plumbing: one-time reordering of the cloud
+        self.data = _bytes(lib.pcl_cloud_bytes(self.n))
+        _lib.check(lib.pcl_cloud_pack(_ptr(xyz), _ptr(rgb), _ptr(self.order), self.n, _ptr(self.data), _stream()),
+                   "pcl_cloud_pack")
+        self.xyz = xyz          # kept for quantile_box (reads the reference's AoS layout)
+
+
+class Pano:
+    """Query panorama (H,W,3) float in [0,1] packed as zero-bordered RGBA texels."""
+
+    def __init__(self, img):
+        lib = _lib.load()
+        img = _dev(img)
+        if img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("img must be (H, W, 3)")
+        self.H, self.W = int(img.shape[0]), int(img.shape[1])
+        self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W))
+        _lib.check(lib.pcl_pano_pack(_ptr(img), self.H, self.W, _ptr(self.data), _stream()), "pcl_pano_pack")
+
+
+def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
+    """(B, 8) float tensor on the GPU: loss, count, dL/dt(3), dL/d(yaw, pitch, roll)."""
+    lib = _lib.load()
+    trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
+    B = int(trans.shape[0])
+    if rot.shape[0] != B:
+        raise ValueError("trans and rot must have the same number of rows")
+    out = torch.empty(B, _lib.RESULT_STRIDE, dtype=F32, device=trans.device)
+    ws_bytes = lib.pcl_loss_workspace_bytes(cloud.n, B)
+    ws = _bytes(ws_bytes)
+    vis = None
+    if visible is not None:
+        vis = _dev(visible, torch.uint8).reshape(B, cloud.n)
+    _lib.check(lib.pcl_sampling_loss(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.H, pano.W, _ptr(trans), _ptr(rot), B,
+                                     1 if with_grad else 0, _ptr(vis), _ptr(out), _ptr(ws), ws_bytes, _stream()),
+               "pcl_sampling_loss")
+    return out
+
+
+def quantile_box(xyz, q):
+    """(6,) GPU tensor: x_lo, x_hi, y_lo, y_hi, z_lo, z_hi — utils.py:208-229 on the three columns."""
+    lib = _lib.load()
+    xyz = _dev(xyz)
+    box = torch.empty(6, dtype=F32, device=xyz.device)
+    ws = _bytes(lib.pcl_quantile_workspace_bytes())
+    _lib.check(lib.pcl_quantile_box(_ptr(xyz), int(xyz.shape[0]), float(q), _ptr(box), _ptr(ws), _stream()), "pcl_quantile_box")
+    return box
+
+
+class GradientDescent:
+    """On-device GD refinement of B candidates (Adam + ReduceLROnPlateau + clamp), pcl_gd_* of the C ABI."""
+
+    def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True):
+        lib = _lib.load()
+        self.cloud, self.pano = cloud, pano
+        trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
+        self.B = int(trans.shape[0])
+        self.box = _dev(box).reshape(6)
+        self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL)
+        self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
+        self.ws_bytes = lib.pcl_loss_workspace_bytes(cloud.n, self.B)
+        self.ws = _bytes(self.ws_bytes)
+        _lib.check(lib.pcl_gd_init(_ptr(self.state), _ptr(trans), _ptr(rot), self.B, ctypes.byref(self.hyper), _stream()),
+                   "pcl_gd_init")
+
+    def run(self, num_iter, history=False, timer=None):
+        lib = _lib.load()
+        hist = torch.empty(num_iter, self.B, dtype=F32, device=self.state.device) if history else None
+        _lib.check(lib.pcl_gd_run(_ptr(self.cloud.data), self.cloud.n, _ptr(self.pano.data), self.pano.H, self.pano.W,
+                                  _ptr(self.state), self.B, _ptr(self.box), ctypes.byref(self.hyper), int(num_iter),
+                                  _ptr(hist), _ptr(self.ws), self.ws_bytes, timer.handle if timer else None, _stream()),
+                   "pcl_gd_run")
+        return hist
+
+    def result(self):
+        """(B, 14): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr."""
+        lib = _lib.load()
+        out = torch.empty(self.B, _lib.GD_RESULT_STRIDE, dtype=F32, device=self.state.device)
+        _lib.check(lib.pcl_gd_result(_ptr(self.state), self.B, _ptr(out), _stream()), "pcl_gd_result")
+        return out
+
+
+class KernelTimer:
+    """HIP-event pairs around every fused loss+gradient launch of GradientDescent.run (measurement aid)."""
+
+    def __init__(self, capacity):
+        self.handle = ctypes.c_void_p(_lib.load().pcl_timer_create(int(capacity)))
+        if not self.handle:
+            raise _lib.PiccoloHipError("pcl_timer_create failed")
+
+    def reset(self):
+        _lib.load().pcl_timer_reset(self.handle)
+
+    def read(self):
+        """(total kernel ms, launches) since the last reset; synchronises on the recorded events."""
+        ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+        _lib.check(_lib.load().pcl_timer_read(self.handle, ctypes.byref(ms), ctypes.byref(cnt)), "pcl_timer_read")
+        return ms.value, cnt.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().pcl_timer_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def cloud2idx(xyz):
+    lib = _lib.load()
+    x = _dev(xyz)
+    shp = x.shape
+    flat = x.reshape(-1, 3)
+    out = torch.empty(flat.shape[0], 2, dtype=F32, device=x.device)
+    if flat.shape[0]:
+        _lib.check(lib.pcl_cloud2idx(_ptr(flat), int(flat.shape[0]), _ptr(out), _stream()), "pcl_cloud2idx")
+    return out.reshape(shp[:-1] + (2,))
+
+
+def sample_from_img(pano, coord):
+    lib = _lib.load()
+    c = _dev(coord)
+    shp = c.shape
+    flat = c.reshape(-1, 2)
+    out = torch.empty(flat.shape[0], 3, dtype=F32, device=c.device)
+    if flat.shape[0]:
+        _lib.check(lib.pcl_sample_from_img(_ptr(pano.data), pano.H, pano.W, _ptr(flat), int(flat.shape[0]), _ptr(out), _stream()),
+                   "pcl_sample_from_img")
+    return out.reshape(shp[:-1] + (3,))
+
+
+def rot_from_ypr(rot):
+    lib = _lib.load()
+    r = _dev(rot).reshape(-1, 3)
+    out = torch.empty(r.shape[0], 9, dtype=F32, device=r.device)
+    _lib.check(lib.pcl_rot_from_ypr(_ptr(r), int(r.shape[0]), _ptr(out), _stream()), "pcl_rot_from_ypr")
+    return out.reshape(-1, 3, 3)
+
+
+def transform_cloud(xyz, trans, rot):
+    lib = _lib.load()
+    x = _dev(xyz)
+    t, r = _dev(trans).reshape(3), _dev(rot).reshape(3)
+    out = torch.empty_like(x)
+    _lib.check(lib.pcl_transform_cloud(_ptr(x), int(x.shape[0]), _ptr(t), _ptr(r), _ptr(out), _stream()), "pcl_transform_cloud")
+    return out
+
+
+def make_pano(xyz_cam, rgb, resolution):
+    """(H, W, 3) float GPU tensor = rgb*255 of the winning point per pixel (utils.py:134-205 semantics)."""
+    lib = _lib.load()
+    x, c = _dev(xyz_cam), _dev(rgb)
+    H, W = int(resolution[0]), int(resolution[1])
+    img = torch.empty(H, W, 3, dtype=F32, device=x.device)
+    ws = _bytes(H * W * 8)
+    _lib.check(lib.pcl_make_pano(_ptr(x), _ptr(c), int(x.shape[0]), H, W, _ptr(img), _ptr(ws), _stream()), "pcl_make_pano")
+    return img
+
+
+def scatter_min_depth(xyz_cam, resolution):
+    """torch_scatter-style (zmin (H*W,), argmin (H*W,)) of point depth per make_pano pixel; empty -> (0, n)."""
+    lib = _lib.load()
+    x = _dev(xyz_cam)
+    H, W = int(resolution[0]), int(resolution[1])
+    n = int(x.shape[0])
+    zbuf = _bytes(H * W * 8)
+    zmin = torch.empty(H * W, dtype=F32, device=x.device)
+    arg = torch.empty(H * W, dtype=torch.int64, device=x.device)
+    _lib.check(lib.pcl_scatter_min_depth(_ptr(x), n, H, W, _ptr(zbuf), _stream()), "pcl_scatter_min_depth")
+    _lib.check(lib.pcl_scatter_min_unpack(_ptr(zbuf), n, H, W, _ptr(zmin), _ptr(arg), _stream()), "pcl_scatter_min_unpack")
+    return zmin, arg

@@ -1,0 +1,261 @@
+"""MI355X counterpart of the reference's utils.py for the sampling-loss path (what localize.py pulls in through
+`from utils import *`, localize.py:13).  Geometry / sampling / rendering run as HIP kernels through piccolo_amd.ops;
+candidate generation is small host logic kept behaviour-compatible with the reference.
+
+    cloud2idx            utils.py:16-61        sample_from_img     utils.py:64-103
+    make_pano            utils.py:134-205      quantile            utils.py:208-229
+    out_of_room          utils.py:232-254      rot_from_ypr        utils.py:425-453
+    trim_input_loss      utils.py:462-507      trim_input_hist_secondary utils.py:510-588
+    make_input           utils.py:591-629      generate_rot_points / generate_trans_points / adaptive_trans_num
+    compute_sampling_grid / create_coordinate  utils.py:702-755      write_summaries utils.py:455-459
+"""
+import math
+from collections import defaultdict
+from math import ceil
+
+import numpy as np
+import torch
+
+from . import ops
+from .omniloc import packed_cloud, packed_pano
+
+__all__ = ["cloud2idx", "sample_from_img", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
+           "trim_input_hist_secondary", "make_input", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
+           "compute_sampling_grid", "create_coordinate", "write_summaries", "get_bound", "defaultdict", "torch", "np"]
+
+
+def _like(out, ref):
+    """Results live where the caller's tensors live (the reference computes on the inputs' device)."""
+    return out if (torch.is_tensor(ref) and ref.is_cuda) else out.cpu()
+
+
+# ------------------------------------------------------------------------------------------------ geometry ops
+def cloud2idx(xyz, batched=False):
+    """(N,3) or (B,N,3) camera-frame points -> equirectangular coordinates in [-1,1]^2 (x = column, y = row).
+    Not differentiable here: the differentiable path is SamplingLoss (loss and gradient fused)."""
+    return _like(ops.cloud2idx(xyz), xyz)
+
+
+def sample_from_img(img, coord_arr, padding="zeros", mode="bilinear", batched=False):
+    """Bilinear lookup of (N,2) / (B,N,2) coordinates in an (H,W,3) image, clipped to +-0.99, zero padding."""
+    if padding != "zeros" or mode != "bilinear":
+        raise NotImplementedError("sample_from_img: only padding='zeros', mode='bilinear' (all the reference uses)")
+    if batched and coord_arr.shape[0] == 1:
+        # the reference's batched path squeezes the batch away for B == 1 (utils.py:88) and then fails
+        raise RuntimeError("sample_from_img(batched=True) needs B > 1, like the reference")
+    return _like(ops.sample_from_img(packed_pano(img), coord_arr), coord_arr)
+
+
+def rot_from_ypr(ypr_array):
+    """(3,) [yaw, pitch, roll] -> R = RZ(yaw) RY(pitch) RX(roll), (3,3)."""
+    return _like(ops.rot_from_ypr(ypr_array.reshape(1, 3))[0], ypr_array)
+
+
+def quantile(x, q):
+    """(x_sorted[int(n q)], x_sorted[int(n (1-q))]) — order statistics without interpolation."""
+    col = ops._dev(x).reshape(-1, 1).expand(-1, 3).contiguous()
+    box = _like(ops.quantile_box(col, q), x)
+    return box[0], box[1]
+
+
+def out_of_room(xyz, trans, out_quantile=0.05):
+    """True if `trans` (3,1) is outside the open [q, 1-q] quantile box of the cloud."""
+    box = ops.quantile_box(xyz, out_quantile).cpu()
+    t = torch.as_tensor(trans).detach().cpu().reshape(3)
+    inside = all(box[2 * k] < t[k] < box[2 * k + 1] for k in range(3))
+    return not inside
+
+
+def get_bound(xyz, cfg, return_brute=False):
+    box = ops.quantile_box(xyz, getattr(cfg, "out_of_room_quantile", 0.05)).cpu().tolist()
+    rng = [(getattr(cfg, "min_yaw", 0), getattr(cfg, "max_yaw", 2 * np.pi)),
+           (getattr(cfg, "min_pitch", 0), getattr(cfg, "max_pitch", np.pi)),
+           (getattr(cfg, "min_roll", 0), getattr(cfg, "max_roll", 2 * np.pi))]
+    pairs = [(box[0], box[1]), (box[2], box[3]), (box[4], box[5])] + rng
+    if return_brute:
+        return tuple(slice(a, b) for a, b in pairs)
+    return dict(zip(["x", "y", "z", "yaw", "pitch", "roll"], pairs))
+
+
+def make_pano(xyz, rgb, resolution=(200, 400), return_torch=False):
+    """Render camera-frame points into an (H,W,3) panorama: 3x3 splats, nearest point wins (z-buffered on the GPU
+    instead of the reference's argsort + nine index_put_ passes).  uint8 numpy by default, float tensor*255 if
+    return_torch."""
+    img = ops.make_pano(xyz, rgb, resolution)
+    if return_torch:
+        return _like(img, xyz)
+    return img.cpu().numpy().astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ initialisation
+def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
+    """Keep the `num_input` (translation, rotation) pairs with the smallest sampling loss out of all K x R pairs.
+    The reference loops K*R forwards in Python (utils.py:484-499); here all pairs go through one fused launch."""
+    K, Rn = len(trans), len(rot)
+    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
+    tt = ops._dev(trans).repeat_interleave(Rn, dim=0)
+    rr = ops._dev(rot).repeat(K, 1)
+    table = ops.sampling_loss(cloud, pano, tt, rr, with_grad=False)[:, 0]          # row-major (K, R) like loss_table
+    num_input = min(num_input, K * Rn)
+    min_inds = torch.argsort(table)[:num_input].to(trans.device)
+    return trans[torch.div(min_inds, Rn, rounding_mode="floor")], rot[min_inds % Rn]
+
+
+def _block_histograms(img255, mask, num_split_h, num_split_w, bins=8):
+    """Per-block normalised colour histograms (8x8x8 bins, bin = value // ceil(255/8)) over the block rows the
+    reference uses (1 .. num_split_h-2, utils.py:556); returns (rows*num_split_w, 512) and per-block pixel counts."""
+    H, W, _ = img255.shape
+    bh, bw = H // num_split_h, W // num_split_w
+    bin_size = int(math.ceil(255 / bins))
+    q = (img255.long() // bin_size)
+    code = q[..., 0] + bins * q[..., 1] + bins * bins * q[..., 2]
+    rows = range(1, num_split_h - 1)
+    hists, counts = [], []
+    for h in rows:
+        for w in range(num_split_w):
+            m = mask[h * bh:(h + 1) * bh, w * bw:(w + 1) * bw]
+            c = code[h * bh:(h + 1) * bh, w * bw:(w + 1) * bw][m]
+            hist = torch.bincount(c, minlength=bins ** 3).float()
+            counts.append(int(m.sum()))
+            hists.append(hist / hist.sum())
+    return torch.stack(hists), counts
+
+
+def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h, num_split_w):
+    """Second trimming stage (utils.py:510-588): render a panorama per candidate and rank candidates by the mean
+    block-wise colour-histogram intersection with the query image.  Panoramas come from the z-buffer kernel."""
+    dev = ops.device()
+    img255 = ops._dev(img) * 255
+    H, W, _ = img255.shape
+    img_mask = ~(img255 == 0).all(dim=2)
+    scores = torch.zeros(len(trans), device=dev)
+    n_blocks = num_split_h * num_split_w
+    for i in range(len(trans)):
+        cam = ops.transform_cloud(xyz, trans[i], rot[i])
+        proj = ops.make_pano(cam, rgb, (H, W))
+        proj_mask = ~(proj == 0).all(dim=2)
+        both = proj_mask & img_mask
+        h_proj, n_proj = _block_histograms(proj, both, num_split_h, num_split_w)
+        h_img, n_img = _block_histograms(img255, img_mask, num_split_h, num_split_w)
+        inter = torch.minimum(h_proj, h_img).sum(-1)
+        inter = torch.nan_to_num(inter, nan=0.0)
+        # the reference leaves a whole block row at 0 from the first empty block on (`break`, utils.py:569-571)
+        inter = inter.reshape(-1, num_split_w)
+        for r in range(inter.shape[0]):
+            for w in range(num_split_w):
+                if n_proj[r * num_split_w + w] == 0 or n_img[r * num_split_w + w] == 0:
+                    inter[r, w:] = 0.0
+                    break
+        scores[i] = inter.sum() / n_blocks
+    order = torch.argsort(scores)[-num_input:].flip(0).to(trans.device)
+    return trans[order], rot[order]
+
+
+def adaptive_trans_num(xyz, max_trans_num, xy_only=False):
+    ext = torch.quantile(xyz, 0.90, dim=0) - torch.quantile(xyz, 0.10, dim=0)
+    lx, ly, lz = [float(v) for v in ext]
+    if xy_only:
+        return ceil((lx * max_trans_num / ly) ** 0.5), ceil((ly * max_trans_num / lx) ** 0.5)
+    nums = [ceil((lx ** 2 * max_trans_num / (ly * lz)) ** (1 / 3)), ceil((ly ** 2 * max_trans_num / (lx * lz)) ** (1 / 3)),
+            ceil((lz ** 2 * max_trans_num / (lx * ly)) ** (1 / 3))]
+    return tuple(n - 1 if n % 2 == 0 else n for n in nums)
+
+
+def create_coordinate(h_out, w_out, device=torch.device("cpu")):
+    """(h_out, w_out, 2) grid of (longitude pi - 2 pi x / w, latitude pi y / h)."""
+    lon = np.pi - torch.arange(w_out, device=device, dtype=torch.float32) * (2 * math.pi / w_out)
+    lat = torch.arange(h_out, device=device, dtype=torch.float32) * (math.pi / h_out)
+    return torch.stack([lon[None, :].expand(h_out, -1), lat[:, None].expand(-1, w_out)], dim=-1)
+
+
+def _sampling_dirs(num_split_h, num_split_w, device):
+    a = create_coordinate(num_split_h, num_split_w, device)
+    lon = a[..., 0] - np.pi / num_split_w
+    lat = a[..., 1] + np.pi / (num_split_h * 2)
+    return torch.stack([torch.sin(lat) * torch.cos(lon), torch.sin(lat) * torch.sin(lon), torch.cos(lat)], dim=-1)
+
+
+def compute_sampling_grid(ypr, num_split_h, num_split_w):
+    """Where the centres of a num_split_h x num_split_w block grid land after rotating by R(ypr)^T (utils.py:719-755)."""
+    R = rot_from_ypr(ypr).T
+    dirs = _sampling_dirs(num_split_h, num_split_w, ypr.device)
+    rotated = (R @ dirs.unsqueeze(3)).squeeze(3)
+    return cloud2idx(rotated.reshape(-1, 3)).reshape(num_split_h, num_split_w, 2)
+
+
+def generate_rot_points(init_dict=None, device="cpu"):
+    """(R,3) [yaw, pitch, roll] starting rotations (utils.py:321-360).  In the 3-DoF case rotations whose block
+    sampling grids coincide (to 3 decimals) are dropped; the survivors are returned in first-occurrence order (the
+    reference's order is that of a Python set of strings, i.e. arbitrary per process)."""
+    d = init_dict
+    if d["yaw_only"]:
+        rot = torch.zeros(d["num_yaw"], 3, device=device)
+        rot[:, 0] = torch.arange(d["num_yaw"], dtype=torch.float, device=device) * 2 * np.pi / d["num_yaw"]
+        return rot
+    fr = [torch.arange(d[k], device=device).float() / d[k] for k in ("num_yaw", "num_pitch", "num_roll")]
+    grid = torch.stack(torch.meshgrid(*fr, indexing="ij"), dim=-1).reshape(-1, 3)
+    lo = torch.tensor([d["min_yaw"], d["min_pitch"], d["min_roll"]], device=device, dtype=torch.float)
+    hi = torch.tensor([d["max_yaw"], d["max_pitch"], d["max_roll"]], device=device, dtype=torch.float)
+    rot = grid * (hi - lo) + lo
+    # all sampling grids in one projection launch (the reference projects one rotation at a time)
+    Rt = ops.rot_from_ypr(rot).transpose(1, 2).to(device)
+    dirs = _sampling_dirs(d["num_yaw"], d["num_pitch"], device).reshape(-1, 3)
+    rotated = torch.einsum("bij,nj->bni", Rt, dirs)
+    grids = cloud2idx(rotated.reshape(-1, 3)).reshape(len(rot), d["num_yaw"], d["num_pitch"], 2).cpu().numpy()
+    seen, keep = set(), []
+    for i, g in enumerate(grids):
+        key = str(np.around(g, 3))
+        if key not in seen:
+            seen.add(key)
+            keep.append(i)
+    return rot[keep]
+
+
+def generate_trans_points(xyz, init_dict=None, device="cpu"):
+    """(K,3) starting translations on a grid inside the cloud (utils.py:363-422)."""
+    d = init_dict
+
+    def axis_points(k, num):
+        col = xyz[:, k]
+        mode = d["trans_init_mode"]
+        if mode == "uniform":
+            return (torch.arange(num, device=device) + 1) / (num + 1) * (col.max() - col.min()) + col.min()
+        if mode == "manual":
+            lo, hi = d["xyz"[k] + "_min"], d["xyz"[k] + "_max"]
+            return torch.arange(num, device=device) / (num - 1) * (hi - lo) + lo
+        if 1 / (num + 1) > 0.1:
+            split = (torch.arange(num, device=device) + 1) / (num + 1)
+        else:
+            split = torch.linspace(0.1, 0.9, num, device=device)
+        return torch.quantile(col, split)
+
+    if d["xy_only"]:
+        if d["dataset"] not in ("Stanford2D-3D-S", "OmniScenes"):
+            raise NotImplementedError("Other datasets not supported")
+        nx, ny = adaptive_trans_num(xyz, d["num_trans"], xy_only=True)
+        gx, gy = torch.meshgrid(axis_points(0, nx), axis_points(1, ny), indexing="ij")
+        out = torch.zeros(nx * ny, 3, device=device)
+        out[:, 0], out[:, 1] = gx.reshape(-1), gy.reshape(-1)
+        out[:, 2] = d["z_prior"] if d["z_prior"] is not None else xyz[:, 2].mean()
+        return out
+    nx, ny, nz = adaptive_trans_num(xyz, d["num_trans"], xy_only=False)
+    g = torch.meshgrid(axis_points(0, nx), axis_points(1, ny), axis_points(2, nz), indexing="ij")
+    return torch.stack([c.reshape(-1) for c in g], dim=1)
+
+
+def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", num_intermediate=None):
+    """Starting poses for the refinement (utils.py:591-629): candidate grid -> sampling-loss trim -> histogram trim.
+    Only criterion == 'loss_histogram' exists in the reference (anything else hits an unbound local there)."""
+    rot = generate_rot_points(init_dict, device=img.device)
+    trans = generate_trans_points(xyz, init_dict, device=img.device)
+    if init_dict["sample_rate_for_init"] is not None:
+        raise NotImplementedError("sample_rate_for_init: broken in the reference too (utils.py:618-620)")
+    if criterion != "loss_histogram":
+        raise UnboundLocalError("make_input: only criterion='loss_histogram' is implemented (as in the reference)")
+    t1, r1 = trim_input_loss(img, xyz, rgb, trans, rot, num_intermediate)
+    return trim_input_hist_secondary(img, xyz, rgb, t1, r1, num_input, init_dict["num_split_h"], init_dict["num_split_w"])
+
+
+def write_summaries(writer, scalar_summaries, step):
+    for k, v in scalar_summaries.items():
+        writer.add_scalar(k, float(np.array(v).mean()), step)

@@ -1,0 +1,371 @@
+"""GPU parity tests (run with -m gpu on the MI355X): the HIP path, called through the C ABI, against
+ (a) the golden vectors the reference produced (tests/golden), and
+ (b) the CPU oracle on the same seeded inputs (sizes the oracle finishes in seconds).
+Tolerances are stated at each assert; integer / index results are exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from piccolo_amd import ops as o
+    o._lib.load()
+    assert torch.cuda.is_available()
+    return o
+
+
+# ------------------------------------------------------------------------------------------- stand-alone ops
+def test_cloud2idx_golden(ops):
+    g = load_golden("g1_cloud2idx.npz")
+    out = ops.cloud2idx(T(g["xyz"])).cpu().numpy()
+    assert np.abs(out - g["coord"]).max() <= 5e-7          # ocml atan2f vs ATen's: <= ~2 ulp of O(1) coordinates
+    assert np.abs(out - g["coord_f64"]).max() <= 5e-7
+    outb = ops.cloud2idx(T(g["xyz_b"])).cpu().numpy()
+    assert outb.shape == g["coord_b"].shape and np.abs(outb - g["coord_b"]).max() <= 5e-7
+
+
+def test_sample_from_img_golden(ops):
+    g = load_golden("g2_sample_from_img.npz")
+    pano = ops.Pano(T(g["img"]))
+    out = ops.sample_from_img(pano, T(g["coord"])).cpu().numpy()
+    assert np.abs(out - g["rgb"]).max() <= 2e-6
+    assert np.array_equal(out == 0, g["rgb"] == 0)          # the exact-zero pattern drives the loss mask
+    outb = ops.sample_from_img(pano, T(g["coord_b"])).cpu().numpy()
+    assert np.abs(outb - g["rgb_b"]).max() <= 2e-6
+
+
+def test_rot_from_ypr(ops, oracle):
+    rng = np.random.default_rng(0)
+    ypr = rng.uniform(-4, 7, size=(64, 3)).astype(np.float32)
+    R = ops.rot_from_ypr(T(ypr)).cpu().numpy()
+    for b in range(64):
+        assert np.abs(R[b] - oracle.rot_from_ypr(ypr[b], np.float64)).max() <= 2e-7
+
+
+def test_quantile_golden_exact(ops):
+    g = load_golden("g6_quantile.npz")
+    for n in (1, 2, 19, 20, 21, 1000, 1001, 4096):
+        x = g["x_%d" % n]
+        xyz = np.stack([x, -x, x * 2], 1).astype(np.float32)
+        for q in (0.05, 0.1, 0.25):
+            box = ops.quantile_box(T(xyz), q).cpu().numpy()
+            ref = g["q_%d_%g" % (n, q)]
+            assert box[0] == ref[0] and box[1] == ref[1], (n, q)        # order statistics: bit exact
+            s = np.sort(-x)
+            assert box[2] == s[int(n * q)] and box[3] == s[int(n * (1 - q))]
+            assert box[4] == 2 * ref[0] and box[5] == 2 * ref[1]
+
+
+def test_quantile_large_exact(ops, oracle):
+    rng = np.random.default_rng(5)
+    xyz = rng.normal(size=(300_001, 3)).astype(np.float32)
+    xyz[:1000, 0] = 0.25           # ties
+    xyz[5, 1] = -0.0
+    box = ops.quantile_box(T(xyz), 0.05).cpu().numpy().reshape(3, 2)
+    ref = oracle.quantile_box(xyz, 0.05)
+    assert np.array_equal(box, ref)
+
+
+# --------------------------------------------------------------------------------------- loss + gradient
+def _loss(ops, xyz, rgb, img, trans, rot, grad=True, sort=True):
+    cloud, pano = ops.Cloud(T(xyz), T(rgb), sort=sort), ops.Pano(T(img))
+    return ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=grad).cpu().numpy()
+
+
+@pytest.mark.parametrize("sort", [False, True])
+def test_sampling_loss_golden(ops, sort):
+    """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run."""
+    g = load_golden("g3_sampling_loss.npz")
+    out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort)
+    assert rel(out[:, 0], g["loss_f64"]) <= 2e-6
+    # gradient: the reference's own fp32-vs-fp64 gap is the yardstick for what fp32 evaluation can deliver
+    gap_t, gap_r = rel(g["grad_t_f32"], g["grad_t_f64"]), rel(g["grad_ypr_f32"], g["grad_ypr_f64"])
+    assert rel(out[:, 2:5], g["grad_t_f64"]) <= max(3 * gap_t, 1e-4)
+    assert rel(out[:, 5:8], g["grad_ypr_f64"]) <= max(3 * gap_r, 1e-4)
+    assert rel(out[:, 2:5], g["grad_t_f32"]) <= 3e-4
+    assert rel(out[:, 5:8], g["grad_ypr_f32"]) <= 3e-4
+
+
+def test_batch_sampling_loss_golden(ops):
+    s, g = load_golden("g3_sampling_loss.npz"), load_golden("g4_batch_sampling_loss.npz")
+    out = _loss(ops, s["xyz"], s["rgb"], s["img"], g["trans"], g["rot"])
+    assert rel(out[:, 0], g["loss_list_f64"]) <= 2e-6
+    assert abs(out[:, 0].sum() - g["loss_f64"]) <= 1e-5
+    assert rel(out[:, 2:5], g["grad_t_f64"]) <= 1e-4
+    assert rel(out[:, 5:8], g["grad_ypr_f64"]) <= 1e-4
+
+
+@pytest.mark.parametrize("n,H,W,B", [(1, 64, 128, 1), (255, 64, 128, 3), (257, 16, 32, 2), (10_000, 128, 256, 5),
+                                     (100_000, 256, 512, 1), (200_003, 256, 512, 8)])
+def test_sampling_loss_vs_oracle(ops, oracle, n, H, W, B):
+    """Ragged sizes (n not a multiple of the block, B odd / even / multiple of 4, H < 100 so border taps occur)."""
+    from piccolo_amd import synth
+    xyz, rgb = synth.box_room(n, seed=n)
+    t_gt, ypr_gt = synth.gt_pose(n % 97)
+    img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=n)
+    out = _loss(ops, xyz, rgb, img, trans, rot)
+    ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64)
+    ref32 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float32)
+    # count: points whose sampled colour is exactly black; a pixel-boundary flip between fp32 and fp64 evaluation can
+    # move a handful of points in or out
+    assert np.abs(out[:, 1] - ref["count"]).max() <= max(2, 2e-5 * n)
+    assert rel(out[:, 0], ref["loss"]) <= 1e-5
+    gap = max(rel(ref32["grad_t"], ref["grad_t"]), rel(ref32["grad_ypr"], ref["grad_ypr"]))
+    tol = max(3 * gap, 2e-4) if n >= 255 else 1e-2
+    assert rel(out[:, 2:5], ref["grad_t"]) <= tol
+    assert rel(out[:, 5:8], ref["grad_ypr"]) <= tol
+
+
+def test_forward_only_matches_grad_pass(ops):
+    g = load_golden("g3_sampling_loss.npz")
+    a = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], grad=True)
+    b = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], grad=False)
+    assert np.array_equal(a[:, :2], b[:, :2]) and (b[:, 2:] == 0).all()
+
+
+def test_all_masked_gives_nan(ops):
+    """An all-black panorama masks every point: the reference returns 0/0 = NaN (omniloc.py:200)."""
+    from piccolo_amd import synth
+    xyz, rgb = synth.box_room(1000, 1)
+    out = _loss(ops, xyz, rgb, np.zeros((32, 64, 3), np.float32), np.zeros((2, 3), np.float32), np.zeros((2, 3), np.float32))
+    assert np.isnan(out[:, 0]).all() and (out[:, 1] == 0).all()
+
+
+def test_visible_mask(ops, oracle):
+    from piccolo_amd import synth
+    n, B = 5000, 4
+    xyz, rgb = synth.box_room(n, 4)
+    t_gt, ypr_gt = synth.gt_pose(4)
+    img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (64, 128)).astype(np.float32) / 255
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=4)
+    vis = (np.random.default_rng(4).random((B, n)) < 0.7).astype(np.uint8)
+    cloud, pano = ops.Cloud(T(xyz), T(rgb), sort=False), ops.Pano(T(img))
+    out = ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=True, visible=T(vis)).cpu().numpy()
+    ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64, visible=vis)
+    assert np.abs(out[:, 1] - ref["count"]).max() <= 1
+    assert rel(out[:, 0], ref["loss"]) <= 1e-5
+    assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+
+
+def test_trim_input_loss_golden(ops):
+    from piccolo_amd import utils
+    g = load_golden("g7_trim_input_loss.npz")
+    tt, tr = utils.trim_input_loss(T(g["img"]), T(g["xyz"]), T(g["rgb"]), T(g["trans"]), T(g["rot"]), 7)
+    assert np.array_equal(tt.cpu().numpy(), g["trimmed_trans"]) and np.array_equal(tr.cpu().numpy(), g["trimmed_rot"])
+
+
+# --------------------------------------------------------------------------------------- GD loops
+def _gd_hist(ops, g, mode_batch, trans, rot, n_it, cfg):
+    cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
+    box = ops.quantile_box(T(g["xyz"]), cfg.out_of_room_quantile)
+    gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=cfg.lr, patience=cfg.patience, factor=cfg.factor,
+                             batch_mode=mode_batch)
+    hist = gd.run(n_it, history=True)
+    return hist.cpu().numpy(), gd.result().cpu().numpy()
+
+
+def test_gd_batch_first_iterations_match_reference(ops):
+    """Free-running on-device GD vs the reference trajectory: parity <= 1e-4 holds for the first iterations only (the
+    trajectory is chaotic: the reference disagrees with itself by 1e-3 after 100 iterations when only the point
+    order changes)."""
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    hist, res = _gd_hist(ops, g, True, g["trans0"], g["rot0"], 3, cfg)
+    assert np.abs(hist - g["bat_fwd_loss"][:3]).max() <= 2e-5
+    # after 3 iterations: forward pose = what iteration 3 of the reference saw
+    assert np.abs(res[:, 0:3] - g["bat_fwd_trans"][3]).max() <= 1e-4
+    assert np.abs(res[:, 3:6] - g["bat_fwd_rot"][3]).max() <= 1e-4
+
+
+def test_gd_batch_clamp_lag(ops):
+    """Pose 1 starts at x = 4.4, outside the box (x_max = 4.0): after one iteration the batch path forwards the
+    unclamped 4.5 while its leaf holds the clamped 4.0 (omniloc.py:260-269) — bit-exact values."""
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    _, res = _gd_hist(ops, g, True, g["trans0"], g["rot0"], 1, cfg)
+    assert res[1, 0] == g["bat2_fwd_trans"][1, 1, 0] == np.float32(4.5)
+    assert res[1, 6] == np.float32(4.0) == g["bat1_input_trans_after"][1, 0]
+    _, res_seq = _gd_hist(ops, g, False, g["trans0"][1:2], g["rot0"][1:2], 1, cfg)
+    assert res_seq[0, 0] == np.float32(4.0) == g["seq1_fwd_trans"][1, 0, 0]
+
+
+@pytest.mark.parametrize("mode_batch", [False, True])
+def test_gd_on_device_equals_oracle_loop_driven_by_hip_gradients(ops, oracle, mode_batch):
+    """The on-device Adam/plateau/clamp epilogue vs the oracle's restatement of the torch optimisers (itself pinned to
+    the reference's 100-iteration trajectories in test_oracle_golden.py), both fed the SAME gradients: the HIP loss
+    kernel evaluated at the oracle loop's poses.  100 iterations, agreement to 1e-5 in pose and exact lr schedule."""
+    from oracle import gd as ogd
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    trans, rot = g["trans0"].copy(), g["rot0"].copy()
+    cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
+
+    def hip_loss_grad(t, r):
+        o = ops.sampling_loss(cloud, pano, T(t), T(r), with_grad=True).cpu().numpy()
+        return o[:, 0], o[:, 2:5], o[:, 5:8]
+
+    trace = []
+    if mode_batch:
+        ref = ogd.omniloc_batch(g["img"], g["xyz"], g["rgb"], trans.copy(), rot.copy(), cfg, loss_grad=hip_loss_grad, trace=trace)
+    else:
+        ref = ogd.omniloc(g["img"], g["xyz"], g["rgb"], trans.copy(), rot.copy(), 1, cfg, loss_grad=hip_loss_grad, trace=trace)
+    t0, r0 = (trans, rot) if mode_batch else (trans[1:2], rot[1:2])
+    hist, res = _gd_hist(ops, g, mode_batch, t0, r0, cfg.num_iter, cfg)
+    ref_loss = np.stack([np.atleast_1d(tr["loss"]) for tr in trace])
+    # identical gradient source, but the trajectory amplifies 1-ulp differences of the scalar update: compare the
+    # first 10 iterations tightly and the lr schedule / final pose loosely
+    assert np.abs(hist[:10] - ref_loss[:10]).max() <= 1e-5
+    k = int(np.argmin(hist[-1]))
+    assert np.abs(res[k, 0:3] - ref[0].reshape(3)).max() <= 5e-3
+    lr_ref = np.atleast_1d(trace[-1]["lr_after"])
+    assert np.allclose(res[:, 13], lr_ref, rtol=1e-6) or np.abs(np.log(res[:, 13] / lr_ref) / np.log(cfg.factor)).max() <= 2
+
+
+def test_gd_epilogue_teacher_forced_single_steps(ops, oracle):
+    """One on-device iteration from every recorded reference state would need state injection; instead run both loops
+    for 1 iteration from 16 random starts and compare the update bit-for-bit-ish (<= 1 ulp of the parameters)."""
+    from oracle import gd as ogd
+    g = load_golden("g5_trajectories.npz")
+    d = json.loads(str(g["cfg"]))
+    d["num_iter"] = 1
+    cfg = Cfg(**d)
+    from piccolo_amd import synth
+    trans, rot = synth.start_poses(g["t_gt"], g["ypr_gt"], 16, seed=99)
+    cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
+
+    def hip_loss_grad(t, r):
+        o = ops.sampling_loss(cloud, pano, T(t), T(r), with_grad=True).cpu().numpy()
+        return o[:, 0], o[:, 2:5], o[:, 5:8]
+
+    it, ir = trans.copy(), rot.copy()
+    ogd.omniloc_batch(g["img"], g["xyz"], g["rgb"], it, ir, cfg, loss_grad=hip_loss_grad)
+    _, res = _gd_hist(ops, g, True, trans, rot, 1, cfg)
+    assert np.abs(res[:, 6:9] - it).max() <= 2e-7 and np.abs(res[:, 9:12] - ir).max() <= 2e-7
+
+
+# --------------------------------------------------------------------------------------- reference call surface
+def test_omniloc_batch_surface(ops, oracle):
+    from piccolo_amd import omniloc as po
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    it, ir = torch.from_numpy(g["trans0"].copy()), torch.from_numpy(g["rot0"].copy())      # CPU tensors: uploaded
+    res = po.omniloc_batch(torch.from_numpy(g["img"]), torch.from_numpy(g["xyz"]), torch.from_numpy(g["rgb"]), it, ir, cfg, {})
+    assert [tuple(r.shape) for r in res] == [(3, 1), (3, 3), ()]
+    assert all(r.device.type == "cpu" and not r.requires_grad and r.dtype == torch.float32 for r in res)
+    np.asarray([res], dtype=object)                     # what localize.py:227 does with it
+    from piccolo_amd import synth
+    t_err, r_err = synth.pose_errors(res[0].numpy(), res[1].numpy(), g["t_gt"], synth.rot_from_ypr_np(g["ypr_gt"]))
+    t_ref, r_ref = synth.pose_errors(g["bat_ret_t"], g["bat_ret_R"], g["t_gt"], synth.rot_from_ypr_np(g["ypr_gt"]))
+    assert t_err <= t_ref + 0.05 and r_err <= r_ref + 1.0, (t_err, r_err, t_ref, r_ref)
+    assert np.abs(res[1].numpy() @ res[1].numpy().T - np.eye(3)).max() <= 1e-6
+    with pytest.raises(AssertionError):
+        po.omniloc_batch(torch.from_numpy(g["img"]), torch.from_numpy(g["xyz"]), torch.from_numpy(g["rgb"]), it[:1], ir[:1],
+                         Cfg(num_input=1), {})
+
+
+def test_omniloc_sequential_surface(ops):
+    from piccolo_amd import omniloc as po
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    it, ir = T(g["trans0"].copy()), T(g["rot0"].copy())
+    res = po.omniloc(T(g["img"]), T(g["xyz"]), T(g["rgb"]), it, ir, 0, cfg, {})
+    assert [tuple(r.shape) for r in res] == [(3, 1), (3, 3), ()] and all(r.device.type == "cpu" for r in res)
+    # row 0 of the caller's tensors now holds the final pose, rows 1.. untouched (omniloc.py:15-19)
+    assert np.abs(it[0].cpu().numpy() - res[0].numpy().reshape(3)).max() <= 0.2
+    assert np.array_equal(it[1:].cpu().numpy(), g["trans0"][1:])
+    from piccolo_amd import synth
+    t_err, _ = synth.pose_errors(res[0].numpy(), res[1].numpy(), g["t_gt"], synth.rot_from_ypr_np(g["ypr_gt"]))
+    t_ref, _ = synth.pose_errors(g["seq0_ret_t"], g["seq0_ret_R"], g["t_gt"], synth.rot_from_ypr_np(g["ypr_gt"]))
+    assert t_err <= t_ref + 0.05
+
+
+def test_modules_autograd(ops):
+    """SamplingLoss / BatchSamplingLoss are differentiable modules: .backward() fills the pose leaves' .grad with the
+    gradients of G3/G4."""
+    from piccolo_amd import omniloc as po
+    g, g4 = load_golden("g3_sampling_loss.npz"), load_golden("g4_batch_sampling_loss.npz")
+    xyz, rgb, img = T(g["xyz"]), T(g["rgb"]), T(g["img"])
+    mod = po.SamplingLoss(xyz, rgb, img, xyz.device, Cfg())
+    t = T(g["trans"][1]).reshape(3, 1).requires_grad_()
+    y, p, r = [T(g["rot"][1, k:k + 1]).requires_grad_() for k in range(3)]
+    loss = mod(t, y, p, r)
+    loss.backward()
+    assert abs(loss.item() - g["loss_f64"][1]) <= 2e-6
+    assert rel(t.grad.cpu().numpy().reshape(3), g["grad_t_f64"][1]) <= 1e-4
+    assert rel([y.grad.item(), p.grad.item(), r.grad.item()], g["grad_ypr_f64"][1]) <= 1e-4
+    B = 4
+    bm = po.BatchSamplingLoss(xyz, rgb, img, xyz.device, Cfg(num_input=B))
+    tb = T(g4["trans"]).unsqueeze(-1).requires_grad_()
+    yb, pb, rb = [T(g4["rot"][:, k:k + 1]).requires_grad_() for k in range(3)]
+    total, lst = bm(tb, yb, pb, rb)
+    total.backward()
+    assert rel(lst.detach().cpu().numpy(), g4["loss_list_f64"]) <= 2e-6
+    assert rel(tb.grad.squeeze(-1).cpu().numpy(), g4["grad_t_f64"]) <= 1e-4
+    assert rel(torch.cat([yb.grad, pb.grad, rb.grad], 1).cpu().numpy(), g4["grad_ypr_f64"]) <= 1e-4
+
+
+# --------------------------------------------------------------------------------------- z-buffer ops
+def test_make_pano_and_scatter_min(ops, oracle):
+    g = load_golden("g8_make_pano.npz")
+    H, W = [int(v) for v in g["resolution"]]
+    img = ops.make_pano(T(g["xyz_cam"]), T(g["rgb"]), (H, W)).cpu().numpy()
+    ref, owner, contested = oracle.make_pano(g["xyz_cam"], g["rgb"], (H, W), return_aux=True)
+    # same winner rule as the oracle (latest pass, nearest, largest index); a point sitting within an ulp of a pixel
+    # boundary may land in the neighbouring pixel (device atan2f vs libm): allow 0.5 % of the pixels
+    assert (np.abs(img - ref).max(-1) > 1e-3).mean() <= 5e-3
+    cands = oracle.make_pano_candidates(g["xyz_cam"], (H, W))
+    rgb255 = g["rgb"] * np.float32(255)
+    bad = sum(1 for k, c in enumerate(cands) if c and not any(np.array_equal(rgb255[i], img.reshape(-1, 3)[k]) for i in c))
+    assert bad <= 0.005 * H * W
+    zmin, arg = ops.scatter_min_depth(T(g["xyz_cam"]), (H, W))
+    zr, ar = oracle.scatter_min_depth(g["xyz_cam"], (H, W))
+    same = arg.cpu().numpy() == ar
+    assert same.mean() >= 0.995
+    assert np.array_equal(zmin.cpu().numpy()[same], zr[same])
+
+
+def test_full_size_properties(ops):
+    """BASELINE cfg-2 sizes (N = 1e6, 2048x1024, B = 32): size-independent properties instead of an oracle run.
+      - a panorama rendered from pose P and sampled at pose P has (near) minimal loss among perturbed poses;
+      - permuting the points changes loss/gradient only by fp32 summation noise;
+      - the loss over a cloud equals the count-weighted mean of the losses over its two halves (linearity)."""
+    from piccolo_amd import synth
+    n, H, W, B = 1_000_000, 1024, 2048, 32
+    xyz, rgb = synth.box_room(n, 7)
+    t_gt, ypr_gt = synth.gt_pose(7)
+    X, C = T(xyz), T(rgb)
+    cam = ops.transform_cloud(X, T(t_gt), T(ypr_gt))
+    img = torch.floor(ops.make_pano(cam, C, (H, W))) / 255
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=7)
+    trans[0], rot[0] = t_gt, ypr_gt
+    pano = ops.Pano(img)
+    full = ops.sampling_loss(ops.Cloud(X, C), pano, T(trans), T(rot)).cpu().numpy()
+    assert full[0, 0] == full[:, 0].min() and full[0, 0] < 0.5 * np.median(full[:, 0])
+    perm = torch.randperm(n, device=X.device, generator=torch.Generator(device=X.device).manual_seed(1))
+    shuf = ops.sampling_loss(ops.Cloud(X[perm], C[perm], sort=False), pano, T(trans), T(rot)).cpu().numpy()
+    assert np.array_equal(full[:, 1], shuf[:, 1])
+    assert rel(full[:, 0], shuf[:, 0]) <= 1e-5 and rel(full[:, 2:], shuf[:, 2:]) <= 2e-4
+    a = ops.sampling_loss(ops.Cloud(X[: n // 2], C[: n // 2]), pano, T(trans), T(rot)).cpu().numpy().astype(np.float64)
+    b = ops.sampling_loss(ops.Cloud(X[n // 2:], C[n // 2:]), pano, T(trans), T(rot)).cpu().numpy().astype(np.float64)
+    cnt = a[:, 1] + b[:, 1]
+    assert np.array_equal(cnt, full[:, 1])
+    assert rel((a[:, 0] * a[:, 1] + b[:, 0] * b[:, 1]) / cnt, full[:, 0]) <= 1e-5
+    comb = (a[:, 2:] * a[:, 1:2] + b[:, 2:] * b[:, 1:2]) / cnt[:, None]
+    assert rel(comb, full[:, 2:]) <= 2e-4
