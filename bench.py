@@ -46,9 +46,10 @@ def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=15.0):
     t0 = time.perf_counter()
     orc.sampling_loss(xyz, rgb, img, trans[:1], rot[:1], dtype=np.float32, grad=True)      # warm-up, also sizes the sample
     t1 = time.perf_counter() - t0
-    n_pose = int(max(1, min(len(trans), budget_s / max(t1, 1e-3))))
+    n_pose = int(max(1, budget_s / max(t1, 1e-3)))
+    reps = np.arange(n_pose) % len(trans)                   # cycle through the candidate poses to fill the budget
     t0 = time.perf_counter()
-    orc.sampling_loss(xyz, rgb, img, trans[:n_pose], rot[:n_pose], dtype=np.float32, grad=True)
+    orc.sampling_loss(xyz, rgb, img, trans[reps], rot[reps], dtype=np.float32, grad=True)
     dt = time.perf_counter() - t0
     pose_evals_per_s = n_pose / dt
     return {"value": pose_evals_per_s / NUM_ITER, "unit": "candidate-poses/s", "cores": cores, "kind": "port",

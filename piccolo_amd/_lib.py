@@ -68,6 +68,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; import it first so this process has ONE runtime (ours resolves to the
+    # already-loaded libamdhip64 by soname).  Loading ours first leaves two runtimes, one of which sees no device.
+    import torch  # noqa: F401
     path = so_path()
     if not os.path.exists(path):
         raise PiccoloHipError(
