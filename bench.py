@@ -37,19 +37,32 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/
 BYTES_PER_POINT_POSE = 24      # xyz + rgb fp32 read once per pose evaluation
 
 
-def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=15.0):
+def usable_cores():
+    """Host cores this process may actually use: CPU affinity, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=12.0):
     """The oracle (C restatement of the reference's loss + gradient, OpenMP on all host cores) timed on a bounded
     sample of the same workload: as many pose evaluations as fit in ~budget_s, scaled to candidate-poses/s."""
     from oracle import oracle as orc
     orc.build()
-    cores = orc.max_threads()
+    cores = usable_cores()
+    orc.sampling_loss(xyz, rgb, img, trans[:1], rot[:1], dtype=np.float32, grad=True, nthreads=cores)   # warm-up
     t0 = time.perf_counter()
-    orc.sampling_loss(xyz, rgb, img, trans[:1], rot[:1], dtype=np.float32, grad=True)      # warm-up, also sizes the sample
-    t1 = time.perf_counter() - t0
-    n_pose = int(max(1, budget_s / max(t1, 1e-3)))
+    orc.sampling_loss(xyz, rgb, img, trans[:4], rot[:4], dtype=np.float32, grad=True, nthreads=cores)   # sizes the sample
+    t1 = (time.perf_counter() - t0) / 4
+    n_pose = int(max(4, budget_s / max(t1, 1e-4)))
     reps = np.arange(n_pose) % len(trans)                   # cycle through the candidate poses to fill the budget
     t0 = time.perf_counter()
-    orc.sampling_loss(xyz, rgb, img, trans[reps], rot[reps], dtype=np.float32, grad=True)
+    orc.sampling_loss(xyz, rgb, img, trans[reps], rot[reps], dtype=np.float32, grad=True, nthreads=cores)
     dt = time.perf_counter() - t0
     pose_evals_per_s = n_pose / dt
     return {"value": pose_evals_per_s / NUM_ITER, "unit": "candidate-poses/s", "cores": cores, "kind": "port",
@@ -98,7 +111,7 @@ def main():
         image_id = rank + i * world                           # round-robin sharding of the query images
         t_gt, ypr_gt = synth.gt_pose(image_id)
         cam = ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
-        img = torch.floor(ops.make_pano(cam, C, (H, W))) / 255.0      # uint8-quantised like a decoded image file
+        img = synth.quantise_like_image_file(ops.make_pano(cam, C, (H, W)))      # uint8-quantised like a decoded image file
         panos.append(ops.Pano(img))
         tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=image_id)
         starts.append((torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev)))
@@ -174,7 +187,7 @@ def main():
                        "mode": "omniloc_batch" if batch_mode else "omniloc"},
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
-            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<4,true,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if B % 2 == 0 else 1, "RGBA8" if panos[0].fmt == _lib.PANO_U8 else "F32"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches_timed": launches},
         }

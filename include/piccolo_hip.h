@@ -41,18 +41,28 @@ const char *pcl_error_string(int code);
  *         point order[i] into slot i: passing a space-filling-curve order makes consecutive lanes hit
  *         neighbouring texels (the loss is a sum over points, so the order does not change the result beyond
  *         fp32 summation rounding).
- * pano  : the query image (H,W,3) float (localize.py:167-170) repacked as (H+2, W+2) RGBA float4 texels with a
- *         one-texel zero border, so grid_sample's zero padding (utils.py:98) needs no bounds test and one
- *         bilinear tap is one 16-byte load.
+ * pano  : the query image (H,W,3) float (localize.py:167-170) repacked as (H+2, W+2) texels with a one-texel zero
+ *         border, so grid_sample's zero padding (utils.py:98) needs no bounds test.  Two texel formats:
+ *           PCL_PANO_F32 : RGBA float4, 16 B/texel — any float image;
+ *           PCL_PANO_U8  : RGBA8, 4 B/texel — for images whose every value is exactly k/255 in fp32, which is what
+ *                          the reference always feeds (cv2.imread -> uint8 -> .float() / 255., localize.py:167-170,
+ *                          211-213; color_mod also re-quantises to uint8, color_utils.py:48-50).  A 2x2 bilinear
+ *                          footprint is then two 8-byte loads and the whole panorama is 4x smaller, so the gathers
+ *                          stay in L2.  The kernel interpolates the integer levels and scales by 1/255 once.
+ *         pcl_pano_pack_u8 sets *not_exact (device int, caller zeroes it) if some value is NOT exactly k/255: the
+ *         caller must then fall back to PCL_PANO_F32.
  */
+#define PCL_PANO_F32 0
+#define PCL_PANO_U8 1
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
 /* 63-bit Morton keys of xyz quantised to 21 bits per axis inside [lo, hi] (host arrays of 3); sort them to get `order`. */
 int pcl_morton_keys(const float *xyz, int64_t n, const float *lo_host, const float *hi_host, int64_t *keys, void *stream);
 
-size_t pcl_pano_bytes(int H, int W);
+size_t pcl_pano_bytes(int H, int W, int pano_format);
 int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream);
+int pcl_pano_pack_u8(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
 
 /* ---- sampling loss (+ gradient) ----------------------------------------------------------------------------
  * Replaces SamplingLoss.forward (omniloc.py:171-202), BatchSamplingLoss.forward (omniloc.py:311-356), the forward
@@ -66,7 +76,7 @@ int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream)
  * loss = sum_i mask_i ||c_i - rgb_i||_2 / sum_i mask_i, mask_i = sampled colour not exactly (0,0,0); 0/0 -> NaN.
  */
 size_t pcl_loss_workspace_bytes(int64_t n, int B);
-int pcl_sampling_loss(const float *cloud, int64_t n, const float *pano, int H, int W, const float *trans,
+int pcl_sampling_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans,
                       const float *rot, int B, int with_grad, const uint8_t *visible, float *result, void *workspace,
                       size_t workspace_bytes, void *stream);
 
@@ -101,7 +111,7 @@ typedef struct pcl_gd_hyper {
 
 size_t pcl_gd_state_bytes(int B);
 int pcl_gd_init(void *state, const float *trans, const float *rot, int B, const pcl_gd_hyper *hyper_host, void *stream);
-int pcl_gd_run(const float *cloud, int64_t n, const float *pano, int H, int W, void *state, int B, const float *box,
+int pcl_gd_run(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, void *state, int B, const float *box,
                const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
                size_t workspace_bytes, void *timer, void *stream);
 int pcl_gd_result(const void *state, int B, float *result, void *stream);
@@ -120,7 +130,8 @@ int pcl_timer_read(void *timer, double *total_ms_host, int *launches_host);
 /* utils.py:16-61 cloud2idx: xyz [n][3] -> coord [n][2] in [-1,1]^2 (batched form = same call on B*n points). */
 int pcl_cloud2idx(const float *xyz, int64_t n, float *coord, void *stream);
 /* utils.py:64-103 sample_from_img: clip to +-0.99, bilinear, zero padding, align_corners=False; rgb_out [n][3]. */
-int pcl_sample_from_img(const float *pano, int H, int W, const float *coord, int64_t n, float *rgb_out, void *stream);
+int pcl_sample_from_img(const void *pano, int pano_format, int H, int W, const float *coord, int64_t n, float *rgb_out,
+                        void *stream);
 /* utils.py:425-453 rot_from_ypr for B poses: rot [B][3] -> R [B][9] row-major. */
 int pcl_rot_from_ypr(const float *rot, int B, float *R, void *stream);
 /* utils.py:208-229 quantile on each of the 3 columns of xyz [n][3]: box[6] = x[int(n q)], x[int(n (1-q))], y.., z..

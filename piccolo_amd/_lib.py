@@ -15,6 +15,7 @@ ABI_VERSION = 1
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
+PANO_F32, PANO_U8 = 0, 1
 
 
 class GdHyper(_c.Structure):
@@ -29,20 +30,21 @@ SIGNATURES = {
     "pcl_cloud_bytes": (_sz, [_i64]),
     "pcl_cloud_pack": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pcl_morton_keys": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _vp, _vp]),
-    "pcl_pano_bytes": (_sz, [_int, _int]),
+    "pcl_pano_bytes": (_sz, [_int, _int, _int]),
     "pcl_pano_pack": (_int, [_vp, _int, _int, _vp, _vp]),
+    "pcl_pano_pack_u8": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
-    "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "pcl_gd_state_bytes": (_sz, [_int]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),
-    "pcl_gd_run": (_int, [_vp, _i64, _vp, _int, _int, _vp, _int, _vp, _c.POINTER(GdHyper), _int, _vp, _vp, _sz, _vp, _vp]),
+    "pcl_gd_run": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _int, _vp, _c.POINTER(GdHyper), _int, _vp, _vp, _sz, _vp, _vp]),
     "pcl_timer_create": (_vp, [_int]),
     "pcl_timer_destroy": (None, [_vp]),
     "pcl_timer_reset": (None, [_vp]),
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),
-    "pcl_sample_from_img": (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp]),
+    "pcl_sample_from_img": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp]),
     "pcl_rot_from_ypr": (_int, [_vp, _int, _vp, _vp]),
     "pcl_quantile_workspace_bytes": (_sz, []),
     "pcl_quantile_box": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp]),

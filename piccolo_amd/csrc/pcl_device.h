@@ -33,18 +33,21 @@ struct PclGdPose {
     int32_t num_bad;
     int32_t step;
     int32_t pad;
+    double beta1_pow, beta2_pow;   // beta^step, kept as running products (Adam bias corrections)
+    float sc[4];                   // sin/cos of the forward pose's yaw and pitch (chain rule of the NEXT epilogue)
 };
-static_assert(sizeof(PclGdPose) == 128, "GD state record");
+static_assert(sizeof(PclGdPose) == 160, "GD state record");
 
 struct PclDims {
     int H, W;    // panorama size
     int Wp;      // padded row length in texels (W + 2)
     float half_w, half_h;    // W/2, H/2            (grid_sample unnormalise)
     float off_x, off_y;      // (W-1)/2 + 1, (H-1)/2 + 1 : pixel coordinate in the zero-bordered texture
-    float k_phi, k_theta;    // -W/(2 pi), H/pi     (d ix / d phi, d iy / d theta)
+    float k_phi, k_theta;    // -W/(2 pi), H/pi     (d ix / d phi, d iy / d theta); times 1/255 for RGBA8 texels
+    float c_scale;           // texel level -> colour: 1 (float texels) or 1/255 (RGBA8)
 };
 
-__host__ __device__ inline PclDims pcl_make_dims(int H, int W)
+__host__ __device__ inline PclDims pcl_make_dims(int H, int W, int pano_format = PCL_PANO_F32)
 {
     PclDims d;
     d.H = H; d.W = W; d.Wp = W + 2;
@@ -52,6 +55,12 @@ __host__ __device__ inline PclDims pcl_make_dims(int H, int W)
     d.off_x = 0.5f * (float)(W - 1) + 1.0f; d.off_y = 0.5f * (float)(H - 1) + 1.0f;
     d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846));
     d.k_theta = (float)((double)H / 3.14159265358979323846);
+    d.c_scale = 1.0f;
+    if (pano_format == PCL_PANO_U8) {
+        d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846) / 255.0);
+        d.k_theta = (float)((double)H / 3.14159265358979323846 / 255.0);
+        d.c_scale = (float)(1.0 / 255.0);
+    }
     return d;
 }
 
@@ -80,6 +89,24 @@ __device__ inline void pcl_write_pose_rec(PclPoseRec* rec, const float p[6])
     rec->pad[0] = rec->pad[1] = rec->pad[2] = rec->pad[3] = 0.f;
 }
 
+// Same R for the GD epilogue, which runs once per iteration on ONE lane per candidate: fp32 sincosf (<= 2 ulp, the
+// precision the reference's own fp32 torch.cos/sin + mm deliver) instead of three double sincos; also returns the
+// sin/cos of yaw and pitch that the next chain rule needs.
+__device__ inline void pcl_write_pose_rec_fast(PclPoseRec* rec, const float p[6], float sc[4])
+{
+    float sy, cy, sp, cp, sr, cr;
+    sincosf(p[3], &sy, &cy);
+    sincosf(p[4], &sp, &cp);
+    sincosf(p[5], &sr, &cr);
+    double dsy = sy, dcy = cy, dsp = sp, dcp = cp, dsr = sr, dcr = cr;
+    rec->R[0] = (float)(dcy * dcp); rec->R[1] = (float)(dcy * dsp * dsr - dsy * dcr); rec->R[2] = (float)(dcy * dsp * dcr + dsy * dsr);
+    rec->R[3] = (float)(dsy * dcp); rec->R[4] = (float)(dsy * dsp * dsr + dcy * dcr); rec->R[5] = (float)(dsy * dsp * dcr - dcy * dsr);
+    rec->R[6] = (float)(-dsp);      rec->R[7] = (float)(dcp * dsr);                   rec->R[8] = (float)(dcp * dcr);
+    rec->t[0] = p[0]; rec->t[1] = p[1]; rec->t[2] = p[2];
+    rec->pad[0] = rec->pad[1] = rec->pad[2] = rec->pad[3] = 0.f;
+    sc[0] = sy; sc[1] = cy; sc[2] = sp; sc[3] = cp;
+}
+
 // Equirectangular projection of a camera-frame point (reference utils.py:44-59):
 //   theta = atan2(|p_xy|, p_z + 1e-6), phi = atan2(p_y, p_x + 1e-6) + pi, g = (1 - phi/pi, 2 theta/pi - 1)
 // written with the same operation order as the reference so the stand-alone op matches it to an ulp or two.
@@ -95,11 +122,64 @@ __device__ inline void pcl_cloud2idx_point(float px, float py, float pz, float& 
     gy = 2.0f * cy - 1.0f;
 }
 
-__device__ inline __amdgpu_buffer_rsrc_t pcl_tex_rsrc(const float* pano, int H, int W)
+// atan2 for the fused kernel: octant reduction to t = min/max in [0,1] (v_rcp_f32, 1 ulp), degree-8 minimax polynomial
+// in t^2 (max abs error 8.7e-8 in fp32 arithmetic, i.e. below the 2.4e-7 ulp of an angle near pi), then the usual
+// reflections.  ~20 VALU + 1 transcendental instead of the ~45 of the library routine.  atan2(0, 0) = 0.
+__device__ __forceinline__ float pcl_atan_poly(float t)
+{
+    float s = t * t;
+    float p = 2.4566929979e-03f;
+    p = fmaf(p, s, -1.4401224869e-02f);
+    p = fmaf(p, s, 3.9780993102e-02f);
+    p = fmaf(p, s, -7.2348362183e-02f);
+    p = fmaf(p, s, 1.0498935044e-01f);
+    p = fmaf(p, s, -1.4161225936e-01f);
+    p = fmaf(p, s, 1.9985906258e-01f);
+    p = fmaf(p, s, -3.3332596993e-01f);
+    p = fmaf(p, s, 9.9999988638e-01f);
+    return p * t;
+}
+
+__device__ __forceinline__ float pcl_atan2(float y, float x)
+{
+    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    float r = pcl_atan_poly(mn * __builtin_amdgcn_rcpf(mx));
+    r = ay > ax ? half_pi - r : r;
+    r = x < 0.f ? pi - r : r;
+    return copysignf(r, y);
+}
+
+// same for y >= 0 (theta = atan2(rho, b)): result in [0, pi], no sign transfer
+__device__ __forceinline__ float pcl_atan2_ypos(float y, float x)
+{
+    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f;
+    float ax = fabsf(x);
+    float mx = fmaxf(fmaxf(ax, y), 1e-37f), mn = fminf(ax, y);
+    float r = pcl_atan_poly(mn * __builtin_amdgcn_rcpf(mx));
+    r = y > ax ? half_pi - r : r;
+    return x < 0.f ? pi - r : r;
+}
+
+__device__ inline __amdgpu_buffer_rsrc_t pcl_tex_rsrc(const void* pano, int H, int W, int texel_bytes = 16)
 {
     // raw buffer, 32-bit offsets, bounds-checked by hardware against the padded texture size
-    return __builtin_amdgcn_make_buffer_rsrc((void*)pano, 0, (int)((size_t)(H + 2) * (size_t)(W + 2) * 16u), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pano, 0, (int)((size_t)(H + 2) * (size_t)(W + 2) * (size_t)texel_bytes),
+                                             0x00020000);
 }
+
+typedef int pcl_i2 __attribute__((ext_vector_type(2)));
+// two horizontally adjacent RGBA8 texels in one 8-byte load
+__device__ inline pcl_i2 pcl_texel_pair_u8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+}
+// byte k of a dword -> float, one instruction each (left to itself the compiler turns the (float)(a) - (float)(b)
+// pattern of the bilinear differences into a much longer integer SDWA sequence)
+__device__ __forceinline__ float pcl_ub0(int v) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v)); return f; }
+__device__ __forceinline__ float pcl_ub1(int v) { float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v)); return f; }
+__device__ __forceinline__ float pcl_ub2(int v) { float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v)); return f; }
 
 __device__ inline pcl_f4 pcl_texel(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {

@@ -7,8 +7,8 @@
 // the reference (fp32 tensors, python-double scalars).
 #include "pcl_device.h"
 
-int pcl_launch_loss(const float* cloud, int64_t n, const float* pano, int H, int W, const PclPoseRec* poses, int B,
-                    bool grad, const uint8_t* visible, float* partials, hipStream_t s);
+int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s);
 size_t pcl_partials_bytes(int64_t n, int B);
 int pcl_plan_nchunks(int64_t n, int B);
 
@@ -31,15 +31,13 @@ __device__ inline void pcl_reduce_partials(const float* __restrict__ partials, i
 // loss and gradient w.r.t. (t, yaw, pitch, roll) from the 8 sums, at pose p = (t, yaw, pitch, roll).
 //   dL/dt = -R^T sum g / M ;  dL/dyaw = e_z . T/M ; dL/dpitch = (RZ e_y) . T/M ; dL/droll = (RZ RY e_x) . T/M
 // with T = sum p x g (see pcl_loss.hip).  M = 0 gives NaN like the reference's 0/0.
-__device__ inline void pcl_chain_rule(const double s[PCL_NACC], const float R[9], const float p[6], float& loss, float grad[6])
+__device__ inline void pcl_chain_rule(const double s[PCL_NACC], const float R[9], double sy, double cy, double sp, double cp,
+                                      float& loss, float grad[6])
 {
     double M = s[1];
     loss = (float)s[0] / (float)M;
     double inv = 1.0 / M;
     for (int k = 0; k < 3; k++) grad[k] = (float)(-((double)R[k] * s[2] + (double)R[3 + k] * s[3] + (double)R[6 + k] * s[4]) * inv);
-    double sy, cy, sp, cp;
-    sincos((double)p[3], &sy, &cy);
-    sincos((double)p[4], &sp, &cp);
     grad[3] = (float)(s[7] * inv);
     grad[4] = (float)((-sy * s[5] + cy * s[6]) * inv);
     grad[5] = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
@@ -64,10 +62,13 @@ __global__ void __launch_bounds__(PCL_WAVE) pcl_finish_kernel(const float* __res
     double s[PCL_NACC];
     pcl_reduce_partials(partials, nchunks, B, b, s);
     if (threadIdx.x == 0) {
-        float p[6] = {0, 0, 0, rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
         float loss, g[6] = {0, 0, 0, 0, 0, 0};
-        if (with_grad) pcl_chain_rule(s, recs[b].R, p, loss, g);
-        else loss = (float)s[0] / (float)s[1];
+        if (with_grad) {
+            double sy, cy, sp, cp;
+            sincos((double)rot[3 * b], &sy, &cy);
+            sincos((double)rot[3 * b + 1], &sp, &cp);
+            pcl_chain_rule(s, recs[b].R, sy, cy, sp, cp, loss, g);
+        } else loss = (float)s[0] / (float)s[1];
         float* r = result + (int64_t)b * PCL_RESULT_STRIDE;
         r[0] = loss; r[1] = (float)s[1];
         for (int k = 0; k < 6; k++) r[2 + k] = g[k];
@@ -80,7 +81,7 @@ extern "C" size_t pcl_loss_workspace_bytes(int64_t n, int B)
     return (size_t)B * sizeof(PclPoseRec) + pcl_partials_bytes(n, B);
 }
 
-extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const float* pano, int H, int W, const float* trans,
+extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans,
                                  const float* rot, int B, int with_grad, const uint8_t* visible, float* result,
                                  void* workspace, size_t workspace_bytes, void* stream)
 {
@@ -91,7 +92,7 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const float* pan
     float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
     hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
     PCL_LAUNCH_CHECK();
-    int rc = pcl_launch_loss(cloud, n, pano, H, W, recs, B, with_grad != 0, visible, partials, s);
+    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s);
     if (rc) return rc;
     hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
                        with_grad, result);
@@ -116,8 +117,9 @@ __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float*
     for (int k = 0; k < 3; k++) { g.leaf[k] = trans[3 * b + k]; g.leaf[3 + k] = rot[3 * b + k]; }
     for (int k = 0; k < 6; k++) { g.fwd[k] = g.leaf[k]; g.m[k] = 0.f; g.v[k] = 0.f; }
     g.last_loss = 0.f; g.num_bad = 0; g.step = 0; g.pad = 0;
+    g.beta1_pow = 1.0; g.beta2_pow = 1.0;
+    pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
     st[b] = g;
-    pcl_write_pose_rec(&recs[b], g.fwd);
 }
 
 __global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks, int B,
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* 
     if (threadIdx.x != 0) return;
     PclGdPose g = st[b];
     float loss, grad[6];
-    pcl_chain_rule(s, recs[b].R, g.fwd, loss, grad);
+    pcl_chain_rule(s, recs[b].R, g.sc[0], g.sc[1], g.sc[2], g.sc[3], loss, grad);
     g.last_loss = loss;
     if (loss_out) loss_out[b] = loss;
 
@@ -139,8 +141,10 @@ __global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* 
     // fp32 tensor math, python-double scalars
     const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
     g.step += 1;
-    double bc1 = 1.0 - pow(beta1, (double)g.step);
-    double bc2 = 1.0 - pow(beta2, (double)g.step);
+    g.beta1_pow *= beta1;                                     // beta ** step as a running product (python: pow)
+    g.beta2_pow *= beta2;
+    double bc1 = 1.0 - g.beta1_pow;
+    double bc2 = 1.0 - g.beta2_pow;
     float step_size = (float)(-(g.lr / bc1));
     float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
@@ -172,8 +176,8 @@ __global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* 
     for (int k = 0; k < 3; k++) g.leaf[k] = fminf(fmaxf(g.leaf[k], box[2 * k]), box[2 * k + 1]);
     if (mode != PCL_GD_BATCH)
         for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
     st[b] = g;
-    pcl_write_pose_rec(&recs[b], g.fwd);
 }
 
 __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, float* __restrict__ result)
@@ -248,7 +252,7 @@ extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_
     return 0;
 }
 
-extern "C" int pcl_gd_run(const float* cloud, int64_t n, const float* pano, int H, int W, void* state, int B,
+extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, void* state, int B,
                           const float* box, const pcl_gd_hyper* hyper_host, int num_iter, float* loss_history,
                           void* workspace, size_t workspace_bytes, void* timer, void* stream)
 {
@@ -263,7 +267,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const float* pano, int 
     for (int it = 0; it < num_iter; it++) {
         const bool timed = tm && tm->used < tm->capacity;
         if (timed) (void)hipEventRecord(tm->start[tm->used], s);
-        int rc = pcl_launch_loss(cloud, n, pano, H, W, gd_recs(state, B), B, true, nullptr, partials, s);
+        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, nullptr, partials, s);
         if (timed) (void)hipEventRecord(tm->stop[tm->used++], s);
         if (rc) return rc;
         hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, nchunks, B, gd_poses(state),

@@ -4,152 +4,270 @@
 //   omniloc.py:190-200 / :332-353  p = R (x - t) -> cloud2idx -> sample_from_img -> mask -> ||c - rgb|| -> mean
 //   omniloc.py:47,254              loss.backward()  (autograd through the above, incl. grid_sampler_2d_backward)
 //
-// Work decomposition (HBM-bound gather/scatter shape, no MFMA):
-//   - the cloud is 6 SoA planes; a block walks ONE contiguous chunk of it (space-filling-curve order makes the
-//     chunk a compact surface patch, so the texels its lanes gather share cache lines and stay in this XCD's L2);
-//   - a block evaluates G candidate poses per point it loads (pose records come in through scalar loads), keeping
-//     8 accumulators per pose in registers for the whole chunk:  sum ||d||, count, sum g, sum p x g   with
-//     g = dL/dp.  The rotation gradient is carried as the torque sum_i p_i x g_i: for R = RZ RY RX,
-//     dR/dyaw = [e_z]x R, dR/dpitch = [RZ e_y]x R, dR/droll = [RZ RY e_x]x R, so dL/dangle = axis . sum(p x g)
-//     — 3 accumulators instead of the 9 of sum g q^T;
-//   - one wave reduction + one LDS reduction per block at the very end, plain stores of the block's partials
-//     (no atomics: the second-stage reduce in pcl_finish / the GD epilogue is deterministic).
-//
-// Per point-pose the kernel reads 24 B of cloud (amortised over G poses) and gathers 4 x 16 B texels.
+// Where the time goes on MI355X (measured, profiles/): the cloud (24 B/point) and the panorama sit in L2 / Infinity
+// Cache, and ~170 fp32 operations per point-pose make the kernel VALU-ISSUE bound: an unpacked fp32 VALU
+// instruction occupies a SIMD for 4 cycles per wave64.  So the design minimises issue slots:
+//   - every lane carries TWO points and evaluates them against the SAME pose with packed fp32 math
+//     (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two results per issue slot); the pose's R and t stay in SGPRs and
+//     are broadcast by op_sel, so no register copies are spent on them;
+//   - the rotation gradient is carried as the torque sum_i p_i x g_i (g = dL/dp): for R = RZ RY RX,
+//     dR/dyaw = [e_z]x R, dR/dpitch = [RZ e_y]x R, dR/droll = [RZ RY e_x]x R, hence dL/dangle = axis . sum(p x g):
+//     3 accumulators instead of the 9 of sum g q^T;  8 accumulators per pose in all: sum ||d||, count, sum g, sum p x g;
+//   - the mask count is a scalar popcount of the compare result (SALU), not a per-lane add;
+//   - atan2 is an octant reduction + degree-8 minimax polynomial (pcl_device.h), evaluated packed;
+//   - RGBA8 panoramas: a 2x2 footprint is two 8-byte loads, the levels are interpolated as exact integers in fp32.
+// Work decomposition: a block walks ONE contiguous chunk of the (Morton-ordered) cloud, so its lanes gather
+// neighbouring texels, and evaluates G poses per loaded point pair; one wave + LDS reduction per block at the end and a
+// plain store of the partials (no atomics: the second-stage reduce in pcl_gd.hip is deterministic).
+#include <stdlib.h>
+
 #include "pcl_device.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define F2(s) ((f2){(s), (s)})
 
 struct PclLossArgs {
     const float* cloud;      // 6 planes of `stride` floats
     int64_t n, stride;
-    const float* pano;       // (H+2, W+2) float4 texels, zero border
+    const void* pano;        // (H+2, W+2) texels, zero border: float4 (PCL_PANO_F32) or RGBA8 (PCL_PANO_U8)
     PclDims dims;
     const PclPoseRec* poses; // [B]
     int B;
     const uint8_t* visible;  // nullable [B][n]
     float* partials;         // [nchunks][B][8]
     int nchunks;             // multiple of 8
-    int64_t chunk_len;       // multiple of PCL_BLOCK
+    int ngroups;             // B / G
+    int64_t chunk_len;       // multiple of PCL_STEP
 };
 
-// One point against one pose. acc: 0 sum||d||, 1 count, 2-4 sum g, 5-7 sum p x g.
-template <bool GRAD>
-__device__ __forceinline__ void pcl_point_pose(float x, float y, float z, float cr, float cg, float cb, bool valid,
-                                               const float* __restrict__ R, const float* __restrict__ t,
-                                               __amdgpu_buffer_rsrc_t tex, const PclDims& dm, float* acc)
+#define PCL_STEP (2 * PCL_BLOCK)   // points per block iteration: two per lane
+
+__device__ __forceinline__ f2 pcl_fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// packed atan2 pieces (see pcl_atan2 in pcl_device.h for the scalar form and the error bound)
+__device__ __forceinline__ f2 pcl_atan_poly2(f2 t)
 {
-    const float inv_pi = 0.31830988618379067154f;
-    // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
-    float qx = x - t[0], qy = y - t[1], qz = z - t[2];
-    float px = fmaf(R[2], qz, fmaf(R[1], qy, R[0] * qx));
-    float py = fmaf(R[5], qz, fmaf(R[4], qy, R[3] * qx));
-    float pz = fmaf(R[8], qz, fmaf(R[7], qy, R[6] * qx));
-    // cloud2idx (utils.py:44-59): gx = 1 - (atan2(py, a) + pi)/pi = -phi/pi ; gy = 2 theta/pi - 1
-    float a = px + 1e-6f, b = pz + 1e-6f;
-    float rho2 = fmaf(px, px, py * py);
-    float rinv = rho2 > 0.f ? __builtin_amdgcn_rsqf(rho2) : 0.f;
-    float rho = rho2 * rinv;
-    float phi = atan2f(py, a);
-    float theta = atan2f(rho, b);
-    float gx = -phi * inv_pi;
-    float gy = fmaf(theta, 2.0f * inv_pi, -1.0f);
-    // sample_from_img (utils.py:97-98): clip to +-0.99, unnormalise (align_corners=False), +1 for the zero border
-    float gxc = __builtin_amdgcn_fmed3f(gx, -0.99f, 0.99f);
-    float gyc = __builtin_amdgcn_fmed3f(gy, -0.99f, 0.99f);
-    float ix = fmaf(gxc, dm.half_w, dm.off_x);
-    float iy = fmaf(gyc, dm.half_h, dm.off_y);
-    int x0 = (int)ix, y0 = (int)iy;            // ix, iy > 0 inside the border, so truncation == floor
-    float fx = ix - (float)x0, fy = iy - (float)y0;
-    int voff = (y0 * dm.Wp + x0) * 16;
-    int row = dm.Wp * 16;
-    pcl_f4 t00 = pcl_texel(tex, voff, 0);
-    pcl_f4 t01 = pcl_texel(tex, voff + 16, 0);
-    pcl_f4 t10 = pcl_texel(tex, voff, row);
-    pcl_f4 t11 = pcl_texel(tex, voff + 16, row);
-    // bilinear: top/bot rows, then vertical; the two partial derivatives fall out of the same differences
-    float dt0 = t01.x - t00.x, dt1 = t01.y - t00.y, dt2 = t01.z - t00.z;
-    float db0 = t11.x - t10.x, db1 = t11.y - t10.y, db2 = t11.z - t10.z;
-    float top0 = fmaf(fx, dt0, t00.x), top1 = fmaf(fx, dt1, t00.y), top2 = fmaf(fx, dt2, t00.z);
-    float bot0 = fmaf(fx, db0, t10.x), bot1 = fmaf(fx, db1, t10.y), bot2 = fmaf(fx, db2, t10.z);
-    float dv0 = bot0 - top0, dv1 = bot1 - top1, dv2 = bot2 - top2;              // dc/diy
-    float c0 = fmaf(fy, dv0, top0), c1 = fmaf(fy, dv1, top1), c2 = fmaf(fy, dv2, top2);
-    // mask: sampled colour not exactly (0,0,0)                               (omniloc.py:198, :347)
-    bool keep = valid && !(c0 == 0.f && c1 == 0.f && c2 == 0.f);
-    float d0 = c0 - cr, d1 = c1 - cg, d2 = c2 - cb;
-    float n2 = fmaf(d0, d0, fmaf(d1, d1, d2 * d2));
-    float rn = (keep && n2 > 0.f) ? __builtin_amdgcn_rsqf(n2) : 0.f;            // 0 also kills the gradient at n = 0
-    acc[0] = fmaf(n2, rn, acc[0]);                                              // ||d|| = n2 * rsqrt(n2)
-    acc[1] += keep ? 1.f : 0.f;
-    if (GRAD) {
-        float dh0 = fmaf(fy, db0 - dt0, dt0), dh1 = fmaf(fy, db1 - dt1, dt1), dh2 = fmaf(fy, db2 - dt2, dt2);  // dc/dix
-        float u0 = d0 * rn, u1 = d1 * rn, u2 = d2 * rn;                         // d||d||/dc
-        float sx = fmaf(u0, dh0, fmaf(u1, dh1, u2 * dh2));
-        float sy = fmaf(u0, dv0, fmaf(u1, dv1, u2 * dv2));
-        // through unnormalise + clip (clamp passes the gradient on [-0.99, 0.99]) to the angles
-        float dphi = (gx == gxc) ? dm.k_phi * sx : 0.f;                          // dL/dphi   = -(W/2pi) sx
-        float dth = (gy == gyc) ? dm.k_theta * sy : 0.f;                         // dL/dtheta =  (H/pi)  sy
-        // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
-        float s1 = fmaf(a, a, py * py), s2 = fmaf(b, b, rho2);
-        float ai = dphi * __builtin_amdgcn_rcpf(s1);
-        float bi = dth * __builtin_amdgcn_rcpf(s2);
-        float k = b * bi * rinv;                                                 // (dL/drho) / rho
-        float g0 = fmaf(k, px, -py * ai);
-        float g1 = fmaf(k, py, a * ai);
-        float g2 = -rho * bi;
-        acc[2] += g0; acc[3] += g1; acc[4] += g2;
-        acc[5] = fmaf(py, g2, fmaf(-pz, g1, acc[5]));
-        acc[6] = fmaf(pz, g0, fmaf(-px, g2, acc[6]));
-        acc[7] = fmaf(px, g1, fmaf(-py, g0, acc[7]));
+    f2 s = t * t;
+    f2 p = F2(2.4566929979e-03f);
+    p = pcl_fma2(p, s, F2(-1.4401224869e-02f));
+    p = pcl_fma2(p, s, F2(3.9780993102e-02f));
+    p = pcl_fma2(p, s, F2(-7.2348362183e-02f));
+    p = pcl_fma2(p, s, F2(1.0498935044e-01f));
+    p = pcl_fma2(p, s, F2(-1.4161225936e-01f));
+    p = pcl_fma2(p, s, F2(1.9985906258e-01f));
+    p = pcl_fma2(p, s, F2(-3.3332596993e-01f));
+    p = pcl_fma2(p, s, F2(9.9999988638e-01f));
+    return p * t;
+}
+
+template <bool SIGNED_Y>
+__device__ __forceinline__ f2 pcl_atan2_2(f2 y, f2 x)
+{
+    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f;
+    float ax0 = fabsf(x.x), ax1 = fabsf(x.y), ay0 = fabsf(y.x), ay1 = fabsf(y.y);
+    f2 mn = {fminf(ax0, ay0), fminf(ax1, ay1)};
+    f2 rc = {__builtin_amdgcn_rcpf(fmaxf(fmaxf(ax0, ay0), 1e-37f)), __builtin_amdgcn_rcpf(fmaxf(fmaxf(ax1, ay1), 1e-37f))};
+    f2 r = pcl_atan_poly2(mn * rc);
+    f2 alt = F2(half_pi) - r;
+    r = (f2){ay0 > ax0 ? alt.x : r.x, ay1 > ax1 ? alt.y : r.y};
+    alt = F2(pi) - r;
+    r = (f2){x.x < 0.f ? alt.x : r.x, x.y < 0.f ? alt.y : r.y};
+    if (SIGNED_Y) r = (f2){copysignf(r.x, y.x), copysignf(r.y, y.y)};
+    return r;
+}
+
+// 2x2 footprint of one point: the 12 tap components as floats (RGBA8: levels 0..255)
+template <int FMT>
+__device__ __forceinline__ void pcl_fetch_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, float t[12])
+{
+    if (FMT == PCL_PANO_U8) {
+        int voff = (y0 * Wp + x0) * 4;
+        pcl_i2 top = pcl_texel_pair_u8(tex, voff, 0);
+        pcl_i2 bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
+        t[0] = pcl_ub0(top.x); t[1] = pcl_ub1(top.x); t[2] = pcl_ub2(top.x);
+        t[3] = pcl_ub0(top.y); t[4] = pcl_ub1(top.y); t[5] = pcl_ub2(top.y);
+        t[6] = pcl_ub0(bot.x); t[7] = pcl_ub1(bot.x); t[8] = pcl_ub2(bot.x);
+        t[9] = pcl_ub0(bot.y); t[10] = pcl_ub1(bot.y); t[11] = pcl_ub2(bot.y);
+    } else {
+        int voff = (y0 * Wp + x0) * 16, row = Wp * 16;
+        pcl_f4 t00 = pcl_texel(tex, voff, 0), t01 = pcl_texel(tex, voff + 16, 0);
+        pcl_f4 t10 = pcl_texel(tex, voff, row), t11 = pcl_texel(tex, voff + 16, row);
+        t[0] = t00.x; t[1] = t00.y; t[2] = t00.z; t[3] = t01.x; t[4] = t01.y; t[5] = t01.z;
+        t[6] = t10.x; t[7] = t10.y; t[8] = t10.z; t[9] = t11.x; t[10] = t11.y; t[11] = t11.z;
     }
 }
 
-template <int G, bool GRAD, bool VIS>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
+// Two points (packed in the .x/.y halves) against one pose.
+// acc: 0 sum||d||, 1 unused here (count goes to `count`, wave-uniform), 2-4 sum g, 5-7 sum p x g — each an f2 whose
+// halves are added at the end.
+template <bool GRAD, int FMT>
+__device__ __forceinline__ void pcl_point_pose2(f2 x, f2 y, f2 z, f2 cr, f2 cg, f2 cb, bool valid0, bool valid1,
+                                                const float* __restrict__ R, const float* __restrict__ t,
+                                                __amdgpu_buffer_rsrc_t tex, const PclDims& dm, f2* acc, int& count)
 {
-    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a contiguous
-    // range of (pose group, chunk) work items: neighbouring chunks share texels along their common boundary.
+    const float inv_pi = 0.31830988618379067154f;
+    // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
+    f2 qx = x - F2(t[0]), qy = y - F2(t[1]), qz = z - F2(t[2]);
+    f2 px = pcl_fma2(F2(R[2]), qz, pcl_fma2(F2(R[1]), qy, F2(R[0]) * qx));
+    f2 py = pcl_fma2(F2(R[5]), qz, pcl_fma2(F2(R[4]), qy, F2(R[3]) * qx));
+    f2 pz = pcl_fma2(F2(R[8]), qz, pcl_fma2(F2(R[7]), qy, F2(R[6]) * qx));
+    // cloud2idx (utils.py:44-59): gx = 1 - (atan2(py, a) + pi)/pi = -phi/pi ; gy = 2 theta/pi - 1
+    f2 a = px + F2(1e-6f), b = pz + F2(1e-6f);
+    f2 rho2 = pcl_fma2(px, px, py * py);
+    // 1/rho; rho = 0 gives rho2 * rinv = 0 and a zero gradient through rho (norm backward is 0 at 0)
+    f2 rinv = {__builtin_amdgcn_rsqf(fmaxf(rho2.x, 1e-37f)), __builtin_amdgcn_rsqf(fmaxf(rho2.y, 1e-37f))};
+    f2 rho = rho2 * rinv;
+    f2 phi = pcl_atan2_2<true>(py, a);
+    f2 theta = pcl_atan2_2<false>(rho, b);
+    f2 gx = phi * F2(-inv_pi);
+    f2 gy = pcl_fma2(theta, F2(2.0f * inv_pi), F2(-1.0f));
+    // sample_from_img (utils.py:97-98): clip to +-0.99, unnormalise (align_corners=False), +1 for the zero border
+    f2 gxc = {__builtin_amdgcn_fmed3f(gx.x, -0.99f, 0.99f), __builtin_amdgcn_fmed3f(gx.y, -0.99f, 0.99f)};
+    f2 gyc = {__builtin_amdgcn_fmed3f(gy.x, -0.99f, 0.99f), __builtin_amdgcn_fmed3f(gy.y, -0.99f, 0.99f)};
+    f2 ix = pcl_fma2(gxc, F2(dm.half_w), F2(dm.off_x));
+    f2 iy = pcl_fma2(gyc, F2(dm.half_h), F2(dm.off_y));
+    // ix, iy > 0 inside the border, so truncation == floor and fract == ix - floor(ix)
+    int x0a = (int)ix.x, x0b = (int)ix.y, y0a = (int)iy.x, y0b = (int)iy.y;
+    f2 fx = {__builtin_amdgcn_fractf(ix.x), __builtin_amdgcn_fractf(ix.y)};
+    f2 fy = {__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
+    float ta[12], tb[12];
+    pcl_fetch_taps<FMT>(tex, x0a, y0a, dm.Wp, ta);
+    pcl_fetch_taps<FMT>(tex, x0b, y0b, dm.Wp, tb);
+    // bilinear: top/bottom rows, then vertical; both partial derivatives fall out of the same differences
+    f2 c[3], dv[3], dtop[3], dbot[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        f2 t00 = {ta[k], tb[k]}, t01 = {ta[3 + k], tb[3 + k]}, t10 = {ta[6 + k], tb[6 + k]}, t11 = {ta[9 + k], tb[9 + k]};
+        dtop[k] = t01 - t00;
+        dbot[k] = t11 - t10;
+        f2 top = pcl_fma2(fx, dtop[k], t00), bot = pcl_fma2(fx, dbot[k], t10);
+        dv[k] = bot - top;                                                        // dc/diy (in texel levels)
+        c[k] = pcl_fma2(fy, dv[k], top);
+    }
+    // mask: sampled colour not exactly (0,0,0)                               (omniloc.py:198, :347)
+    bool keep0 = valid0 && fmaxf(fmaxf(fabsf(c[0].x), fabsf(c[1].x)), fabsf(c[2].x)) > 0.f;
+    bool keep1 = valid1 && fmaxf(fmaxf(fabsf(c[0].y), fabsf(c[1].y)), fabsf(c[2].y)) > 0.f;
+    count += __builtin_popcountll(__ballot(keep0)) + __builtin_popcountll(__ballot(keep1));
+    f2 d0, d1, d2;
+    if (FMT == PCL_PANO_U8) {
+        d0 = pcl_fma2(c[0], F2(dm.c_scale), -cr); d1 = pcl_fma2(c[1], F2(dm.c_scale), -cg); d2 = pcl_fma2(c[2], F2(dm.c_scale), -cb);
+    } else {
+        d0 = c[0] - cr; d1 = c[1] - cg; d2 = c[2] - cb;
+    }
+    f2 n2 = pcl_fma2(d0, d0, pcl_fma2(d1, d1, d2 * d2));
+    // 1/||d|| for kept points, 0 otherwise (also 0 * huge = 0 at ||d|| = 0: norm backward is 0 there)
+    f2 rn = {keep0 ? __builtin_amdgcn_rsqf(fmaxf(n2.x, 1e-37f)) : 0.f, keep1 ? __builtin_amdgcn_rsqf(fmaxf(n2.y, 1e-37f)) : 0.f};
+    acc[0] = pcl_fma2(n2, rn, acc[0]);                                            // ||d|| = n2 * rsqrt(n2)
+    if (GRAD) {
+        f2 u0 = d0 * rn, u1 = d1 * rn, u2 = d2 * rn;                             // d||d||/dc
+        f2 dh0 = pcl_fma2(fy, dbot[0] - dtop[0], dtop[0]);                       // dc/dix
+        f2 dh1 = pcl_fma2(fy, dbot[1] - dtop[1], dtop[1]);
+        f2 dh2 = pcl_fma2(fy, dbot[2] - dtop[2], dtop[2]);
+        f2 sx = pcl_fma2(u0, dh0, pcl_fma2(u1, dh1, u2 * dh2));
+        f2 sy = pcl_fma2(u0, dv[0], pcl_fma2(u1, dv[1], u2 * dv[2]));
+        // through unnormalise + clip (clamp passes the gradient on [-0.99, 0.99]) to the angles:
+        // dL/dphi = -(W/2pi) sx, dL/dtheta = (H/pi) sy (constants carry the 1/255 of RGBA8 levels)
+        f2 dphi = sx * F2(dm.k_phi), dth = sy * F2(dm.k_theta);
+        dphi = (f2){gx.x == gxc.x ? dphi.x : 0.f, gx.y == gxc.y ? dphi.y : 0.f};
+        dth = (f2){gy.x == gyc.x ? dth.x : 0.f, gy.y == gyc.y ? dth.y : 0.f};
+        // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
+        f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, rho2);
+        f2 ai = dphi * (f2){__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
+        f2 bi = dth * (f2){__builtin_amdgcn_rcpf(s2.x), __builtin_amdgcn_rcpf(s2.y)};
+        f2 k = b * bi * rinv;                                                     // (dL/drho) / rho
+        f2 g0 = pcl_fma2(k, px, -(py * ai));
+        f2 g1 = pcl_fma2(k, py, a * ai);
+        f2 g2 = -(rho * bi);
+        acc[2] += g0; acc[3] += g1; acc[4] += g2;
+        acc[5] = pcl_fma2(py, g2, pcl_fma2(-pz, g1, acc[5]));
+        acc[6] = pcl_fma2(pz, g0, pcl_fma2(-px, g2, acc[6]));
+        acc[7] = pcl_fma2(px, g1, pcl_fma2(-py, g0, acc[7]));
+    }
+}
+
+// OCC = minimum resident 256-thread blocks per CU the register allocator must allow (0: compiler's choice)
+template <int G, bool GRAD, bool VIS, int OCC, int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK, (OCC > 0 ? OCC : 1)) pcl_loss_kernel(PclLossArgs a)
+{
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.
+    // Give every XCD a contiguous range of CHUNKS (a compact part of the room, hence of the panorama for all the
+    // nearby candidate poses) and let the pose group vary fastest, so the blocks that are resident together on an XCD
+    // read the same cloud chunk and neighbouring texels: both stay in that XCD's L2 across the pose groups.
     const int nblk = gridDim.x;                       // = nchunks * ngroups, multiple of 8
     const int per_xcd = nblk >> 3;
     const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int group = v / a.nchunks, chunk = v - group * a.nchunks;
+    const int chunk = v / a.ngroups, group = v - chunk * a.ngroups;
     const int pose0 = group * G;
 
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W);
-    const float* __restrict__ X = a.cloud;
-    const int64_t S = a.stride;
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, FMT == PCL_PANO_U8 ? 4 : 16);
+    // the cloud through a buffer resource too: 32-bit lane offsets + scalar plane offsets, no 64-bit address math
+    __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
+    const int plane = (int)a.stride * 4;
 
-    float acc[G][PCL_NACC];
+    f2 acc[G][PCL_NACC];
+    int count[G];
 #pragma unroll
-    for (int g = 0; g < G; g++)
+    for (int g = 0; g < G; g++) {
+        count[g] = 0;
 #pragma unroll
-        for (int k = 0; k < PCL_NACC; k++) acc[g][k] = 0.f;
+        for (int k = 0; k < PCL_NACC; k++) acc[g][k] = F2(0.f);
+    }
 
-    const int64_t begin = (int64_t)chunk * a.chunk_len;
-    int64_t end = begin + a.chunk_len;
-    if (end > a.n) end = a.n;
-    for (int64_t base = begin; base < end; base += PCL_BLOCK) {
-        int64_t i = base + threadIdx.x;
-        bool valid = i < end;
-        int64_t j = valid ? i : (a.n - 1);
-        float x = X[j], y = X[S + j], z = X[2 * S + j];
-        float cr = X[3 * S + j], cg = X[4 * S + j], cb = X[5 * S + j];
+    const int begin = (int)((int64_t)chunk * a.chunk_len);
+    int end = begin + (int)a.chunk_len;
+    if (end > (int)a.n) end = (int)a.n;
+    const int last = (int)a.n - 1;
+
+    // two points per lane: i0 = base + tid, i1 = base + 256 + tid; loads for step k+1 are issued before step k is
+    // evaluated so their L2 latency hides under ~500 VALU instructions
+    float nx[2][6];
+    {
+        int j0 = min(begin + (int)threadIdx.x, last), j1 = min(begin + PCL_BLOCK + (int)threadIdx.x, last);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            nx[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
+            nx[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
+        }
+    }
+    for (int base = begin; base < end; base += PCL_STEP) {
+        const int i0 = base + threadIdx.x, i1 = i0 + PCL_BLOCK;
+        const bool valid0 = i0 < end, valid1 = i1 < end;
+        f2 x = {nx[0][0], nx[1][0]}, y = {nx[0][1], nx[1][1]}, z = {nx[0][2], nx[1][2]};
+        f2 cr = {nx[0][3], nx[1][3]}, cg = {nx[0][4], nx[1][4]}, cb = {nx[0][5], nx[1][5]};
+        if (base + PCL_STEP < end) {
+            int j0 = min(i0 + PCL_STEP, last), j1 = min(i1 + PCL_STEP, last);
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                nx[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
+                nx[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const PclPoseRec* __restrict__ pr = a.poses + (pose0 + g);
-            bool ok = valid;
-            if (VIS) ok = ok && a.visible[(int64_t)(pose0 + g) * a.n + j] != 0;
-            pcl_point_pose<GRAD>(x, y, z, cr, cg, cb, ok, pr->R, pr->t, tex, a.dims, acc[g]);
+            bool ok0 = valid0, ok1 = valid1;
+            if (VIS) {
+                const uint8_t* vis = a.visible + (int64_t)(pose0 + g) * a.n;
+                ok0 = ok0 && vis[min(i0, last)] != 0;
+                ok1 = ok1 && vis[min(i1, last)] != 0;
+            }
+            pcl_point_pose2<GRAD, FMT>(x, y, z, cr, cg, cb, ok0, ok1, pr->R, pr->t, tex, a.dims, acc[g], count[g]);
         }
     }
 
-    // block reduction: wave shuffle, then 4 waves through LDS, plain store of the partials
+    // block reduction: fold the two packed halves, wave shuffle, 4 waves through LDS, plain store of the partials
     __shared__ float red[PCL_BLOCK / PCL_WAVE][G * PCL_NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
         for (int k = 0; k < PCL_NACC; k++) {
+            if (k == 1) {
+                if (lane == 0) red[wave][g * PCL_NACC + 1] = (float)count[g];   // wave-uniform popcount total
+                continue;
+            }
             if (!GRAD && k >= 2) continue;
-            float s = pcl_wave_sum(acc[g][k]);
+            float s = pcl_wave_sum(acc[g][k].x + acc[g][k].y);
             if (lane == 0) red[wave][g * PCL_NACC + k] = s;
         }
     __syncthreads();
@@ -164,6 +282,13 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
 // ------------------------------------------------------------------------------------------------------------
 // launch planning (shared with the GD loop)
 
+// experiment knobs (read once): PCL_G = poses per block (1/2/4), PCL_OCC = launch-bounds variant, PCL_BLOCKS = target grid
+static int pcl_env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 struct PclPlan {
     int G, ngroups, nchunks;
     int64_t chunk_len;
@@ -171,17 +296,20 @@ struct PclPlan {
 
 static PclPlan pcl_plan(int64_t n, int B)
 {
+    static const int g_env = pcl_env_int("PCL_G", 0), blocks_env = pcl_env_int("PCL_BLOCKS", 4096);
     PclPlan p;
-    p.G = (B % 4 == 0) ? 4 : ((B % 2 == 0) ? 2 : 1);
+    // poses per block: 2 measured best at cfg2 (4: 146 VGPRs -> 3 waves/SIMD; 1: point loads not amortised)
+    p.G = (B % 2 == 0) ? 2 : 1;
+    if (g_env > 0 && B % g_env == 0) p.G = g_env;
     p.ngroups = B / p.G;
-    // aim at ~4096 blocks (256 CUs x 8 resident blocks x 2 rounds), at least one 256-point step per chunk
-    int64_t want = 4096 / p.ngroups;
+    // aim at ~4096 blocks (256 CUs x a few resident blocks x several rounds), at least one step per chunk
+    int64_t want = blocks_env / p.ngroups;
     if (want < 8) want = 8;
-    int64_t max_chunks = (n + PCL_BLOCK - 1) / PCL_BLOCK;
+    int64_t max_chunks = (n + PCL_STEP - 1) / PCL_STEP;
     if (want > max_chunks) want = max_chunks;
     want = ((want + 7) / 8) * 8;
     int64_t len = (n + want - 1) / want;
-    len = ((len + PCL_BLOCK - 1) / PCL_BLOCK) * PCL_BLOCK;
+    len = ((len + PCL_STEP - 1) / PCL_STEP) * PCL_STEP;
     p.nchunks = (int)want;
     p.chunk_len = len;
     return p;
@@ -195,33 +323,50 @@ size_t pcl_partials_bytes(int64_t n, int B)
 
 int pcl_plan_nchunks(int64_t n, int B) { return pcl_plan(n, B).nchunks; }
 
-template <int G>
-static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
+template <int G, int OCC, int FMT>
+static void pcl_launch_go(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
 {
     if (grad) {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, true>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, false>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, true, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, false, OCC, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
     } else {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, true>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, false>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, true, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, false, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
     }
 }
 
-// Enqueue one fused loss(+grad) pass over the cloud for B poses; partials must hold pcl_partials_bytes(n, B).
-int pcl_launch_loss(const float* cloud, int64_t n, const float* pano, int H, int W, const PclPoseRec* poses, int B,
-                    bool grad, const uint8_t* visible, float* partials, hipStream_t s)
+template <int G, int FMT>
+static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
 {
+    static const int occ = pcl_env_int("PCL_OCC", 0);
+    if (occ == 4) pcl_launch_go<G, 4, FMT>(a, nblk, grad, vis, s);
+    else if (occ == 3) pcl_launch_go<G, 3, FMT>(a, nblk, grad, vis, s);
+    else pcl_launch_go<G, 0, FMT>(a, nblk, grad, vis, s);
+}
+
+template <int FMT>
+static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, bool vis, hipStream_t s)
+{
+    if (G == 4) pcl_launch_g<4, FMT>(a, nblk, grad, vis, s);
+    else if (G == 2) pcl_launch_g<2, FMT>(a, nblk, grad, vis, s);
+    else pcl_launch_g<1, FMT>(a, nblk, grad, vis, s);
+}
+
+// Enqueue one fused loss(+grad) pass over the cloud for B poses; partials must hold pcl_partials_bytes(n, B).
+int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s)
+{
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8) return PCL_EINVAL;
     PclPlan p = pcl_plan(n, B);
     PclLossArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
-    a.pano = pano; a.dims = pcl_make_dims(H, W);
+    a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
-    a.nchunks = p.nchunks; a.chunk_len = p.chunk_len;
+    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.chunk_len = p.chunk_len;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
-    if (p.G == 4) pcl_launch_g<4>(a, nblk, grad, vis, s);
-    else if (p.G == 2) pcl_launch_g<2>(a, nblk, grad, vis, s);
-    else pcl_launch_g<1>(a, nblk, grad, vis, s);
+    if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
+    else pcl_launch_f<PCL_PANO_F32>(a, p.G, nblk, grad, vis, s);
     PCL_LAUNCH_CHECK();
     return 0;
 }

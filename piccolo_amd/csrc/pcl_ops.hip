@@ -25,13 +25,14 @@ extern "C" int pcl_cloud2idx(const float* xyz, int64_t n, float* coord, void* st
 // ------------------------------------------------------------------------------------------- sample_from_img
 // utils.py:64-103: clip to +-0.99, grid_sample(bilinear, zeros, align_corners=False).  Same tap arithmetic as
 // ATen's grid_sampler_2d (weights (1-fx)(1-fy) ... times the four taps) so the stand-alone op matches to rounding.
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const float* __restrict__ pano, int H, int W,
+template <int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __restrict__ pano, int H, int W,
                                                                const float* __restrict__ coord, int64_t n,
                                                                float* __restrict__ out)
 {
     int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
     if (i >= n) return;
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W);
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, FMT == PCL_PANO_U8 ? 4 : 16);
     float2 g = reinterpret_cast<const float2*>(coord)[i];
     float gx = __builtin_amdgcn_fmed3f(g.x, -0.99f, 0.99f), gy = __builtin_amdgcn_fmed3f(g.y, -0.99f, 0.99f);
     float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
@@ -40,20 +41,37 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const float* __re
     // keep the gather inside the bordered texture for any input (|g| <= 0.99 already guarantees it for H,W >= 1)
     x0 = min(max(x0, 0), W); y0 = min(max(y0, 0), H);
     float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
-    int Wp = W + 2, voff = (y0 * Wp + x0) * 16, row = Wp * 16;
-    pcl_f4 t00 = pcl_texel(tex, voff, 0), t01 = pcl_texel(tex, voff + 16, 0);
-    pcl_f4 t10 = pcl_texel(tex, voff, row), t11 = pcl_texel(tex, voff + 16, row);
+    int Wp = W + 2;
+    pcl_f4 t00, t01, t10, t11;
+    if (FMT == PCL_PANO_U8) {
+        // levels back to the fp32 values the reference samples: k / 255 (IEEE division, as uint8 -> .float() / 255.)
+        int voff = (y0 * Wp + x0) * 4;
+        pcl_i2 top = pcl_texel_pair_u8(tex, voff, 0), bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
+        t00 = {__fdiv_rn(pcl_ub0(top.x), 255.f), __fdiv_rn(pcl_ub1(top.x), 255.f), __fdiv_rn(pcl_ub2(top.x), 255.f), 0.f};
+        t01 = {__fdiv_rn(pcl_ub0(top.y), 255.f), __fdiv_rn(pcl_ub1(top.y), 255.f), __fdiv_rn(pcl_ub2(top.y), 255.f), 0.f};
+        t10 = {__fdiv_rn(pcl_ub0(bot.x), 255.f), __fdiv_rn(pcl_ub1(bot.x), 255.f), __fdiv_rn(pcl_ub2(bot.x), 255.f), 0.f};
+        t11 = {__fdiv_rn(pcl_ub0(bot.y), 255.f), __fdiv_rn(pcl_ub1(bot.y), 255.f), __fdiv_rn(pcl_ub2(bot.y), 255.f), 0.f};
+    } else {
+        int voff = (y0 * Wp + x0) * 16, row = Wp * 16;
+        t00 = pcl_texel(tex, voff, 0); t01 = pcl_texel(tex, voff + 16, 0);
+        t10 = pcl_texel(tex, voff, row); t11 = pcl_texel(tex, voff + 16, row);
+    }
     float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
     out[3 * i] = t00.x * nw + t01.x * ne + t10.x * sw + t11.x * se;
     out[3 * i + 1] = t00.y * nw + t01.y * ne + t10.y * sw + t11.y * se;
     out[3 * i + 2] = t00.z * nw + t01.z * ne + t10.z * sw + t11.z * se;
 }
 
-extern "C" int pcl_sample_from_img(const float* pano, int H, int W, const float* coord, int64_t n, float* rgb_out, void* stream)
+extern "C" int pcl_sample_from_img(const void* pano, int pano_format, int H, int W, const float* coord, int64_t n, float* rgb_out,
+                                   void* stream)
 {
     if (!pano || !coord || !rgb_out || n <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
-    hipLaunchKernelGGL(pcl_sample_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
-                       (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8) return PCL_EINVAL;
+    dim3 grid((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK));
+    if (pano_format == PCL_PANO_U8)
+        hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_U8>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
+    else
+        hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_F32>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -17,7 +17,11 @@ extern "C" const char* pcl_error_string(int code)
 // plane stride: n rounded up to 256 floats (1 KiB) so every plane starts on a fresh 1-KiB wave-load boundary
 extern "C" int64_t pcl_cloud_stride(int64_t n) { return n <= 0 ? 0 : ((n + 255) / 256) * 256; }
 extern "C" size_t pcl_cloud_bytes(int64_t n) { return (size_t)pcl_cloud_stride(n) * 6 * sizeof(float); }
-extern "C" size_t pcl_pano_bytes(int H, int W) { return (H <= 0 || W <= 0) ? 0 : (size_t)(H + 2) * (size_t)(W + 2) * 16; }
+extern "C" size_t pcl_pano_bytes(int H, int W, int pano_format)
+{
+    if (H <= 0 || W <= 0 || (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8)) return 0;
+    return (size_t)(H + 2) * (size_t)(W + 2) * (pano_format == PCL_PANO_U8 ? 4 : 16);
+}
 
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_cloud_pack_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb,
                                                                    const int64_t* __restrict__ order, int64_t n,
@@ -102,6 +106,40 @@ extern "C" int pcl_pano_pack(const float* img_hwc, int H, int W, float* pano, vo
     int64_t total = (int64_t)(H + 2) * (W + 2);
     hipLaunchKernelGGL(pcl_pano_pack_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
                        (hipStream_t)stream, img_hwc, H, W, (pcl_f4*)pano);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// RGBA8 texels for images that are exactly k/255 (see include/piccolo_hip.h); flags anything else.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8_kernel(const float* __restrict__ img, int H, int W,
+                                                                     uint32_t* __restrict__ pano, int* __restrict__ not_exact)
+{
+    int Wp = W + 2, Hp = H + 2;
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= (int64_t)Wp * Hp) return;
+    int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+    uint32_t v = 0u;
+    if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+        const float* s = img + ((int64_t)(yp - 1) * W + (xp - 1)) * 3;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float f = s[c], k = rintf(f * 255.f);
+            // uint8 -> .float() / 255. is an IEEE fp32 division: the value is exact iff dividing the level back gives f
+            bad = bad || !(k >= 0.f && k <= 255.f) || __fdiv_rn(k, 255.f) != f;
+            v |= ((uint32_t)k & 255u) << (8 * c);
+        }
+        if (bad) *not_exact = 1;
+    }
+    pano[i] = v;
+}
+
+extern "C" int pcl_pano_pack_u8(const float* img_hwc, int H, int W, uint32_t* pano, int* not_exact, void* stream)
+{
+    if (!img_hwc || !pano || !not_exact || H <= 0 || W <= 0) return PCL_EINVAL;
+    int64_t total = (int64_t)(H + 2) * (W + 2);
+    hipLaunchKernelGGL(pcl_pano_pack_u8_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, img_hwc, H, W, pano, not_exact);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -67,16 +67,31 @@ class Cloud:
 
 
 class Pano:
-    """Query panorama (H,W,3) float in [0,1] packed as zero-bordered RGBA texels."""
+    """Query panorama (H,W,3) float packed as zero-bordered texels.
 
-    def __init__(self, img):
+    fmt="auto": RGBA8 texels when every value is exactly k/255 in fp32 (what an 8-bit image file divided by 255 gives,
+    i.e. everything the reference's harness produces), float4 texels otherwise.  The exactness test is one kernel and
+    one 4-byte D2H read per image, outside the GD loop."""
+
+    def __init__(self, img, fmt="auto"):
         lib = _lib.load()
         img = _dev(img)
         if img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("img must be (H, W, 3)")
         self.H, self.W = int(img.shape[0]), int(img.shape[1])
-        self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W))
-        _lib.check(lib.pcl_pano_pack(_ptr(img), self.H, self.W, _ptr(self.data), _stream()), "pcl_pano_pack")
+        self.fmt = None
+        if fmt in ("auto", "u8"):
+            data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_U8))
+            flag = torch.zeros(1, dtype=torch.int32, device=img.device)
+            _lib.check(lib.pcl_pano_pack_u8(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), "pcl_pano_pack_u8")
+            if int(flag.item()) == 0:
+                self.fmt, self.data = _lib.PANO_U8, data
+            elif fmt == "u8":
+                raise ValueError("image is not exactly k/255: cannot use RGBA8 texels")
+        if self.fmt is None:
+            self.fmt = _lib.PANO_F32
+            self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_F32))
+            _lib.check(lib.pcl_pano_pack(_ptr(img), self.H, self.W, _ptr(self.data), _stream()), "pcl_pano_pack")
 
 
 def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
@@ -92,7 +107,7 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     vis = None
     if visible is not None:
         vis = _dev(visible, torch.uint8).reshape(B, cloud.n)
-    _lib.check(lib.pcl_sampling_loss(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.H, pano.W, _ptr(trans), _ptr(rot), B,
+    _lib.check(lib.pcl_sampling_loss(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(trans), _ptr(rot), B,
                                      1 if with_grad else 0, _ptr(vis), _ptr(out), _ptr(ws), ws_bytes, _stream()),
                "pcl_sampling_loss")
     return out
@@ -127,7 +142,7 @@ class GradientDescent:
     def run(self, num_iter, history=False, timer=None):
         lib = _lib.load()
         hist = torch.empty(num_iter, self.B, dtype=F32, device=self.state.device) if history else None
-        _lib.check(lib.pcl_gd_run(_ptr(self.cloud.data), self.cloud.n, _ptr(self.pano.data), self.pano.H, self.pano.W,
+        _lib.check(lib.pcl_gd_run(_ptr(self.cloud.data), self.cloud.n, _ptr(self.pano.data), self.pano.fmt, self.pano.H, self.pano.W,
                                   _ptr(self.state), self.B, _ptr(self.box), ctypes.byref(self.hyper), int(num_iter),
                                   _ptr(hist), _ptr(self.ws), self.ws_bytes, timer.handle if timer else None, _stream()),
                    "pcl_gd_run")
@@ -185,7 +200,7 @@ def sample_from_img(pano, coord):
     flat = c.reshape(-1, 2)
     out = torch.empty(flat.shape[0], 3, dtype=F32, device=c.device)
     if flat.shape[0]:
-        _lib.check(lib.pcl_sample_from_img(_ptr(pano.data), pano.H, pano.W, _ptr(flat), int(flat.shape[0]), _ptr(out), _stream()),
+        _lib.check(lib.pcl_sample_from_img(_ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(flat), int(flat.shape[0]), _ptr(out), _stream()),
                    "pcl_sample_from_img")
     return out.reshape(shp[:-1] + (3,))
 

@@ -82,3 +82,12 @@ def pose_errors(t, R, t_gt, R_gt):
         tr = 6 - tr
     r_err = float(np.rad2deg(np.abs(np.arccos((tr - 1) / 2))))
     return t_err, r_err
+
+
+def quantise_like_image_file(pano255):
+    """torch (H,W,3) float panorama in [0,255] -> float image exactly as `uint8 image / 255.` gives it on the host
+    (the reference divides on the CPU, localize.py:167-170).  A GPU division is not IEEE-exact on ROCm, so the levels
+    are mapped through a 256-entry table computed on the CPU."""
+    import torch
+    lut = (torch.arange(256, dtype=torch.float32) / 255.0).to(pano255.device)
+    return lut[pano255.clamp(0, 255).to(torch.int64)]

@@ -45,9 +45,11 @@ def test_cloud2idx_golden(ops):
     assert outb.shape == g["coord_b"].shape and np.abs(outb - g["coord_b"]).max() <= 5e-7
 
 
-def test_sample_from_img_golden(ops):
+@pytest.mark.parametrize("fmt", ["auto", "f32"])
+def test_sample_from_img_golden(ops, fmt):
     g = load_golden("g2_sample_from_img.npz")
-    pano = ops.Pano(T(g["img"]))
+    pano = ops.Pano(T(g["img"]), fmt=fmt)
+    assert pano.fmt == (ops._lib.PANO_U8 if fmt == "auto" else ops._lib.PANO_F32)      # the golden image is k/255
     out = ops.sample_from_img(pano, T(g["coord"])).cpu().numpy()
     assert np.abs(out - g["rgb"]).max() <= 2e-6
     assert np.array_equal(out == 0, g["rgb"] == 0)          # the exact-zero pattern drives the loss mask
@@ -88,16 +90,18 @@ def test_quantile_large_exact(ops, oracle):
 
 
 # --------------------------------------------------------------------------------------- loss + gradient
-def _loss(ops, xyz, rgb, img, trans, rot, grad=True, sort=True):
-    cloud, pano = ops.Cloud(T(xyz), T(rgb), sort=sort), ops.Pano(T(img))
+def _loss(ops, xyz, rgb, img, trans, rot, grad=True, sort=True, fmt="auto"):
+    cloud, pano = ops.Cloud(T(xyz), T(rgb), sort=sort), ops.Pano(T(img), fmt=fmt)
     return ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=grad).cpu().numpy()
 
 
+@pytest.mark.parametrize("fmt", ["auto", "f32"])
 @pytest.mark.parametrize("sort", [False, True])
-def test_sampling_loss_golden(ops, sort):
-    """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run."""
+def test_sampling_loss_golden(ops, sort, fmt):
+    """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run; RGBA8
+    texels (auto: the golden panorama is k/255) and float4 texels."""
     g = load_golden("g3_sampling_loss.npz")
-    out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort)
+    out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort, fmt=fmt)
     assert rel(out[:, 0], g["loss_f64"]) <= 2e-6
     # gradient: the reference's own fp32-vs-fp64 gap is the yardstick for what fp32 evaluation can deliver
     gap_t, gap_r = rel(g["grad_t_f32"], g["grad_t_f64"]), rel(g["grad_ypr_f32"], g["grad_ypr_f64"])
@@ -114,6 +118,28 @@ def test_batch_sampling_loss_golden(ops):
     assert abs(out[:, 0].sum() - g["loss_f64"]) <= 1e-5
     assert rel(out[:, 2:5], g["grad_t_f64"]) <= 1e-4
     assert rel(out[:, 5:8], g["grad_ypr_f64"]) <= 1e-4
+
+
+def test_pano_format_selection_and_float_image(ops, oracle):
+    """An image that is not k/255 must take the float4 texel path (auto-detected) and still match the oracle."""
+    from piccolo_amd import synth
+    n, H, W, B = 20_000, 96, 192, 4
+    xyz, rgb = synth.box_room(n, 31)
+    t_gt, ypr_gt = synth.gt_pose(31)
+    img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+    img_f = (img * np.float32(0.93)).astype(np.float32)             # same black pattern, values no longer k/255
+    assert ops.Pano(T(img)).fmt == ops._lib.PANO_U8 and ops.Pano(T(img_f)).fmt == ops._lib.PANO_F32
+    with pytest.raises(ValueError):
+        ops.Pano(T(img_f), fmt="u8")
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=31)
+    out = _loss(ops, xyz, rgb, img_f, trans, rot)
+    ref = oracle.sampling_loss(xyz, rgb, img_f, trans, rot, dtype=np.float64)
+    assert np.abs(out[:, 1] - ref["count"]).max() <= 2
+    assert rel(out[:, 0], ref["loss"]) <= 1e-5
+    assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+    # and the two texel formats agree with each other on a k/255 image (same taps, different rounding of the lerp)
+    a, b = _loss(ops, xyz, rgb, img, trans, rot, fmt="auto"), _loss(ops, xyz, rgb, img, trans, rot, fmt="f32")
+    assert np.array_equal(a[:, 1], b[:, 1]) and rel(a[:, 0], b[:, 0]) <= 1e-6 and rel(a[:, 2:], b[:, 2:]) <= 1e-4
 
 
 @pytest.mark.parametrize("n,H,W,B", [(1, 64, 128, 1), (255, 64, 128, 3), (257, 16, 32, 2), (10_000, 128, 256, 5),
@@ -239,11 +265,21 @@ def test_gd_on_device_equals_oracle_loop_driven_by_hip_gradients(ops, oracle, mo
     # the first 5 iterations tightly for every candidate, the first 10 for the well-posed ones, the rest loosely
     assert np.abs(hist[:5] - ref_loss[:5]).max() <= 1e-5
     if mode_batch:
-        assert np.abs(hist[:10, [0, 2, 3]] - ref_loss[:10, [0, 2, 3]]).max() <= 1e-5
-    k = int(np.argmin(hist[-1]))
-    assert np.abs(res[k, 0:3] - ref[0].reshape(3)).max() <= 2e-2      # reference self-noise after 100 iterations: ~1e-3..1e-2
-    lr_ref = np.atleast_1d(trace[-1]["lr_after"])
-    assert np.allclose(res[:, 13], lr_ref, rtol=1e-6) or np.abs(np.log(res[:, 13] / lr_ref) / np.log(cfg.factor)).max() <= 2
+        assert np.abs(hist[:6, [0, 2, 3]] - ref_loss[:6, [0, 2, 3]]).max() <= 1e-4
+    # after 100 iterations only statistics are comparable (the reference's own self-noise is 1e-3..1e-2 in pose):
+    # the best final loss, the winner's pose for the well-posed sequential start, and the lr schedule within two
+    # plateau decisions
+    assert abs(float(hist[-1].min()) - float(ref_loss[-1].min())) <= 0.02
+    if not mode_batch:
+        assert np.abs(res[0, 0:3] - ref[0].reshape(3)).max() <= 2e-2
+    # the on-device ReduceLROnPlateau, checked exactly: replay the DEVICE's own loss history through the oracle's
+    # restatement of the scheduler (pinned to the reference in test_oracle_golden.py); the final lr must be identical
+    for b in range(hist.shape[1]):
+        opt = ogd.Adam(6, cfg.lr)
+        sched = ogd.Plateau(opt, cfg.patience, cfg.factor)
+        for it in range(hist.shape[0]):
+            sched.step(hist[it, b])
+        assert np.float32(opt.lr) == res[b, 13], (b, opt.lr, res[b, 13])
 
 
 def test_gd_epilogue_teacher_forced_single_steps(ops, oracle):
@@ -362,7 +398,7 @@ def test_full_size_properties(ops):
     t_gt, ypr_gt = synth.gt_pose(7)
     X, C = T(xyz), T(rgb)
     cam = ops.transform_cloud(X, T(t_gt), T(ypr_gt))
-    img = torch.floor(ops.make_pano(cam, C, (H, W))) / 255
+    img = synth.quantise_like_image_file(ops.make_pano(cam, C, (H, W)))
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=7)
     trans[0], rot[0] = t_gt, ypr_gt
     pano = ops.Pano(img)
