@@ -1,0 +1,100 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/piccolo_hip.h
+declares, the ctypes binding covers exactly that set, and size queries behave (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "piccolo_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcl_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from piccolo_amd import _lib, build
+    build.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_declares_the_path():
+    names = declared_symbols()
+    for must in ("pcl_cloud_pack", "pcl_pano_pack", "pcl_pano_pack_u8", "pcl_sampling_loss", "pcl_gd_init", "pcl_gd_run",
+                 "pcl_gd_result", "pcl_cloud2idx", "pcl_sample_from_img", "pcl_quantile_box", "pcl_scatter_min_depth",
+                 "pcl_make_pano", "pcl_rot_from_ypr"):
+        assert must in names
+
+
+def test_binding_covers_exactly_the_header(lib):
+    from piccolo_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from piccolo_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.so_path()], text=True)
+    exported = set(re.findall(r"\bT (pcl_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+    for name in declared_symbols():
+        assert getattr(lib, name) is not None
+
+
+def test_library_is_a_gfx950_code_object(lib):
+    from piccolo_amd import _lib
+    blob = open(_lib.so_path(), "rb").read()
+    assert b"gfx950" in blob and b"pcl_loss_kernel" in blob
+
+
+def test_size_queries_and_argument_checks(lib):
+    from piccolo_amd import _lib
+    assert lib.pcl_abi_version() == _lib.ABI_VERSION
+    assert lib.pcl_cloud_stride(1) == 256 and lib.pcl_cloud_stride(256) == 256 and lib.pcl_cloud_stride(257) == 512
+    assert lib.pcl_cloud_bytes(1000) == 1024 * 6 * 4
+    assert lib.pcl_pano_bytes(4, 8, _lib.PANO_F32) == 6 * 10 * 16 and lib.pcl_pano_bytes(4, 8, _lib.PANO_U8) == 6 * 10 * 4
+    assert lib.pcl_pano_bytes(4, 8, 7) == 0 and lib.pcl_pano_bytes(0, 8, 0) == 0
+    assert lib.pcl_gd_state_bytes(32) == 32 * (160 + 64)
+    ws1, ws2 = lib.pcl_loss_workspace_bytes(1_000_000, 32), lib.pcl_loss_workspace_bytes(1_000_000, 256)
+    assert 0 < ws1 < ws2 < 64 << 20
+    assert lib.pcl_loss_workspace_bytes(0, 32) == 0
+    # bad arguments are rejected before anything touches a device
+    assert lib.pcl_sampling_loss(None, 10, None, 0, 4, 8, None, None, 1, 1, None, None, None, 0, None) == -1
+    assert lib.pcl_gd_run(None, 10, None, 0, 4, 8, None, 1, None, None, 1, None, None, 0, None, None) == -1
+    assert lib.pcl_quantile_box(None, 10, 0.05, None, None, None) == -1
+    assert b"invalid argument" in lib.pcl_error_string(-1) and b"workspace" in lib.pcl_error_string(-2)
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch, tmp_path):
+    """No CPU fallback: without a GPU every op raises; without the .so the loader raises."""
+    import torch
+    from piccolo_amd import _lib, ops
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.PiccoloHipError):
+            ops.cloud2idx(torch.zeros(4, 3))
+        with pytest.raises(_lib.PiccoloHipError):
+            ops.Cloud(torch.zeros(4, 3), torch.zeros(4, 3))
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "so_path", lambda: str(tmp_path / "missing.so"))
+    with pytest.raises(_lib.PiccoloHipError):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under piccolo_amd/, dropin/ or main.py may reference it."""
+    bad = []
+    for root in ("piccolo_amd", "dropin"):
+        for dp, _, files in os.walk(os.path.join(REPO, root)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    text = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b|oracle\.|pcl_oracle", text, re.M):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+    assert "oracle" not in open(os.path.join(REPO, "main.py")).read()

@@ -1,0 +1,84 @@
+"""GPU tests of the callers either side of the hot path: candidate generation, the two trimming
+stages of make_input, and the synthetic harness."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, load_golden
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_roll=2 * np.pi, min_roll=0,
+            z_prior=None, sample_rate_for_init=None, trans_init_mode="quantile",
+            x_max=None, x_min=None, y_max=None, y_min=None, z_max=None, z_min=None, num_split_h=4, num_split_w=4)
+STANFORD = dict(BASE, xy_only=False, num_trans=50, yaw_only=False, num_yaw=4, num_pitch=4, num_roll=4, dataset="Stanford2D-3D-S")
+OMNI = dict(BASE, xy_only=True, num_trans=150, yaw_only=True, num_yaw=8, num_pitch=8, num_roll=8, dataset="OmniScenes", z_prior=1.5)
+
+
+def _rows(a):
+    a = np.asarray(a, np.float64)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_candidate_generation_matches_reference():
+    """G10: the reference's own generate_rot_points / generate_trans_points on the same cloud.  The rotation set is
+    compared as a set (the reference orders it by iterating a Python set of strings)."""
+    from piccolo_amd import utils
+    g = load_golden("g10_candidates.npz")
+    xyz = torch.from_numpy(g["xyz"]).cuda()
+    for tag, d in (("stanford", STANFORD), ("omniscenes", OMNI)):
+        rot = utils.generate_rot_points(d, device=xyz.device).cpu().numpy()
+        tr = utils.generate_trans_points(xyz, d, device=xyz.device).cpu().numpy()
+        assert rot.shape == g[tag + "_rot"].shape and tr.shape == g[tag + "_trans"].shape
+        assert np.abs(_rows(rot) - _rows(g[tag + "_rot"])).max() <= 1e-6
+        assert np.abs(tr - g[tag + "_trans"]).max() <= 1e-5
+
+
+def test_make_input_finds_the_neighbourhood_of_the_true_pose(oracle):
+    """make_input = candidate grid -> sampling-loss trim -> histogram trim.  On a synthetic room the best surviving
+    candidate must be the grid pose nearest to the ground truth (coarse grid: ~1 m / 90 deg spacing)."""
+    from piccolo_amd import synth, utils
+    n, H, W = 50_000, 128, 256
+    xyz, rgb = synth.box_room(n, 3)
+    t_gt = np.array([0.9, -0.6, 0.0], np.float32)
+    ypr_gt = np.array([np.pi / 2, 0.0, 0.0], np.float32)
+    img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+    X, C, I = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(img).cuda()
+    trans, rot = utils.make_input(I, X, C, 6, dict(STANFORD), "loss_histogram", 20)
+    assert trans.shape == (6, 3) and rot.shape == (6, 3)
+    R_gt = synth.rot_from_ypr_np(ypr_gt)
+    errs = [synth.pose_errors(trans[i].cpu().numpy(), synth.rot_from_ypr_np(rot[i].cpu().numpy()), t_gt, R_gt) for i in range(6)]
+    assert min(e[0] for e in errs) < 1.2 and min(e[1] for e in errs) < 5.0, errs
+    with pytest.raises(UnboundLocalError):
+        utils.make_input(I, X, C, 6, dict(STANFORD), "histogram", 20)
+
+
+def test_utils_surface(oracle):
+    from piccolo_amd import synth, utils
+    g = load_golden("g6_quantile.npz")
+    x = torch.from_numpy(g["x_1001"])                       # CPU tensor in, CPU tensors out
+    lo, hi = utils.quantile(x, 0.05)
+    assert lo.device.type == "cpu" and lo.item() == g["q_1001_0.05"][0] and hi.item() == g["q_1001_0.05"][1]
+    xyz, rgb = synth.box_room(2000, 5)
+    X = torch.from_numpy(xyz).cuda()
+    inside = torch.tensor([[0.0], [0.0], [0.0]])
+    outside = torch.tensor([[4.5], [0.0], [0.0]])
+    assert utils.out_of_room(X, inside) is False and utils.out_of_room(X, outside) is True
+    pano = utils.make_pano(X, torch.from_numpy(rgb).cuda(), resolution=(32, 64))
+    assert pano.dtype == np.uint8 and pano.shape == (32, 64, 3)
+    R = utils.rot_from_ypr(torch.tensor([0.3, -0.2, 0.1]))
+    assert np.abs(R.numpy() - oracle.rot_from_ypr([0.3, -0.2, 0.1], np.float64)).max() <= 2e-7
+    with pytest.raises(NotImplementedError):
+        utils.sample_from_img(torch.zeros(4, 8, 3), torch.zeros(3, 2), padding="border")
+
+
+def test_localize_synthetic_converges():
+    from piccolo_amd.localize import localize_synthetic
+    cfg = Cfg(num_points=100_000, pano_height=256, pano_width=512, num_images=3, num_input=8, parallel=True,
+              lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05)
+    table = localize_synthetic(cfg).cpu().numpy()
+    assert table.shape == (3, 16)
+    assert np.median(table[:, 13]) < 0.05 and np.median(table[:, 14]) < 1.0          # ~0.01 m / 0.3 deg expected
+    seq = Cfg(**{**cfg.__dict__, "parallel": False, "num_images": 1, "num_input": 2})
+    t2 = localize_synthetic(seq).cpu().numpy()
+    assert t2[0, 13] < 0.1
