@@ -82,3 +82,28 @@ def test_localize_synthetic_converges():
     seq = Cfg(**{**cfg.__dict__, "parallel": False, "num_images": 1, "num_input": 2})
     t2 = localize_synthetic(seq).cpu().numpy()
     assert t2[0, 13] < 0.1
+
+
+def test_integration_md_stub_runs(oracle):
+    """The ctypes stub printed in INTEGRATION.md is executable documentation: extract it, run it, check it."""
+    import os
+    import re
+    from conftest import REPO
+    from piccolo_amd import _lib, synth
+    _lib.load()
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# piccolo_hip_stub\.py.*?)```", text, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(REPO)
+    try:
+        exec(compile(code, "piccolo_hip_stub.py", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    g = load_golden("g3_sampling_loss.npz")
+    dev = torch.device("cuda")
+    fused = ns["FusedSamplingLoss"](torch.from_numpy(g["xyz"]).to(dev), torch.from_numpy(g["rgb"]).to(dev),
+                                    torch.from_numpy(g["img"]).to(dev))
+    out = fused(torch.from_numpy(g["trans"]).to(dev), torch.from_numpy(g["rot"]).to(dev)).cpu().numpy()
+    assert np.abs(out[:, 0] - g["loss_f64"]).max() <= 2e-6
+    assert np.abs(out[:, 2:5] - g["grad_t_f64"]).max() / np.abs(g["grad_t_f64"]).max() <= 1e-4
