@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("PCL_BENCH_STREAMS", "1")),
+                    help="independent query images refined concurrently on this many HIP streams per GPU (measured: no gain, "
+                         "2545 vs 2536 candidate-poses/s at 1 vs 2 streams; kept as a knob)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from the rocprofv3 PMC passes (written by profiles/collect.sh)")
     args = ap.parse_args()
@@ -121,15 +124,27 @@ def main():
         del cam, img
     results = torch.zeros(n_img, 16, device=dev)
     timer = ops.KernelTimer(NUM_ITER * K)
+    # Independent images go to separate HIP streams: one image's optimiser epilogue, kernel boundaries and the tail of
+    # its loss kernel overlap with the other image's loss kernel (each GD loop is a strict launch-after-launch chain).
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
     def refine(i, tm=None):
-        gd = ops.GradientDescent(cloud, panos[i], starts[i][0], starts[i][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
-                                 batch_mode=batch_mode)
-        gd.run(NUM_ITER, timer=tm)
-        res = gd.result()
-        k = torch.argmin(res[:, 12])                           # winner = smallest loss of the last forward
-        results[i, :6] = res[k, :6]
-        results[i, 6] = res[k, 12]
+        st = streams[i % len(streams)]
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            gd = ops.GradientDescent(cloud, panos[i], starts[i][0], starts[i][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
+                                     batch_mode=batch_mode)
+            gd.run(NUM_ITER, timer=tm)
+            res = gd.result()
+            k = torch.argmin(res[:, 12])                       # winner = smallest loss of the last forward
+            results[i, :6] = res[k, :6]
+            results[i, 6] = res[k, 12]
+            for t in (gd.state, gd.ws, res):
+                t.record_stream(st)
+
+    def join_streams():
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
 
     def barrier():
         if dist is not None:
@@ -137,12 +152,14 @@ def main():
 
     for i in range(Wm):
         refine(i)
+    join_streams()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(Wm, n_img):
         refine(i, timer)
+    join_streams()
     if dist is not None:                                       # the path's only collective: gather the results
         gathered = torch.empty(world * n_img, 16, device=dev)
         dist.all_gather_into_tensor(gathered, results)
@@ -184,7 +201,7 @@ def main():
             "config": {"workload": "%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD iterations per query image"
                                    % (args.workload, N, W, H, B, NUM_ITER),
                        "images_per_gpu": K, "sharding": "query images round-robin over ranks, RCCL all_gather of results",
-                       "mode": "omniloc_batch" if batch_mode else "omniloc"},
+                       "mode": "omniloc_batch" if batch_mode else "omniloc", "streams_per_gpu": len(streams)},
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
             "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if B % 2 == 0 else 1, "RGBA8" if panos[0].fmt == _lib.PANO_U8 else "F32"), "achieved": achieved, "peak": HBM_PEAK_GBS,

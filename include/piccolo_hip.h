@@ -35,7 +35,7 @@ int pcl_abi_version(void);
 const char *pcl_error_string(int code);
 
 /* ---- data layout in HBM ------------------------------------------------------------------------------------
- * cloud : 6 planes (x, y, z, r, g, b) of pcl_cloud_stride(n) floats each — SoA so that a wavefront's 64 lanes
+ * cloud : 6 planes (x, y, z, -r, -g, -b) of pcl_cloud_stride(n) floats each (colours negated: the loss needs c - rgb) — SoA so that a wavefront's 64 lanes
  *         read 256 contiguous bytes per plane.  Built once per point cloud from the reference's row-major
  *         (N,3) xyz and rgb tensors (localize.py:159-164).  `order` (nullable, int64[n]) gathers
  *         point order[i] into slot i: passing a space-filling-curve order makes consecutive lanes hit

@@ -27,7 +27,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define F2(s) ((f2){(s), (s)})
 
 struct PclLossArgs {
-    const float* cloud;      // 6 planes of `stride` floats
+    const float* cloud;      // 6 planes of `stride` floats: x, y, z, -r, -g, -b
     int64_t n, stride;
     const void* pano;        // (H+2, W+2) texels, zero border: float4 (PCL_PANO_F32) or RGBA8 (PCL_PANO_U8)
     PclDims dims;
@@ -76,48 +76,66 @@ __device__ __forceinline__ f2 pcl_atan2_2(f2 y, f2 x)
     return r;
 }
 
-// 2x2 footprint of one point: the 12 tap components as floats (RGBA8: levels 0..255)
-template <int FMT>
-__device__ __forceinline__ void pcl_fetch_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, float t[12])
+// Raw 2x2 footprint of one point as it arrives from memory: RGBA8 -> two 8-byte texel pairs; float4 -> four taps.
+template <int FMT> struct PclTaps;
+template <> struct PclTaps<PCL_PANO_U8> { pcl_i2 top, bot; };
+template <> struct PclTaps<PCL_PANO_F32> { int voff, row; };  // float4 texels are fetched where they are consumed
+
+__device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_U8>& o)
 {
-    if (FMT == PCL_PANO_U8) {
-        int voff = (y0 * Wp + x0) * 4;
-        pcl_i2 top = pcl_texel_pair_u8(tex, voff, 0);
-        pcl_i2 bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
-        t[0] = pcl_ub0(top.x); t[1] = pcl_ub1(top.x); t[2] = pcl_ub2(top.x);
-        t[3] = pcl_ub0(top.y); t[4] = pcl_ub1(top.y); t[5] = pcl_ub2(top.y);
-        t[6] = pcl_ub0(bot.x); t[7] = pcl_ub1(bot.x); t[8] = pcl_ub2(bot.x);
-        t[9] = pcl_ub0(bot.y); t[10] = pcl_ub1(bot.y); t[11] = pcl_ub2(bot.y);
-    } else {
-        int voff = (y0 * Wp + x0) * 16, row = Wp * 16;
-        pcl_f4 t00 = pcl_texel(tex, voff, 0), t01 = pcl_texel(tex, voff + 16, 0);
-        pcl_f4 t10 = pcl_texel(tex, voff, row), t11 = pcl_texel(tex, voff + 16, row);
-        t[0] = t00.x; t[1] = t00.y; t[2] = t00.z; t[3] = t01.x; t[4] = t01.y; t[5] = t01.z;
-        t[6] = t10.x; t[7] = t10.y; t[8] = t10.z; t[9] = t11.x; t[10] = t11.y; t[11] = t11.z;
-    }
+    int voff = (y0 * Wp + x0) * 4;
+    o.top = pcl_texel_pair_u8(tex, voff, 0);
+    o.bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
+}
+__device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_F32>& o)
+{
+    o.voff = (y0 * Wp + x0) * 16;
+    o.row = Wp * 16;
+}
+// the 12 tap components as floats (RGBA8: levels 0..255, one v_cvt_f32_ubyteN each)
+__device__ __forceinline__ void pcl_unpack_taps(__amdgpu_buffer_rsrc_t, const PclTaps<PCL_PANO_U8>& r, float t[12])
+{
+    t[0] = pcl_ub0(r.top.x); t[1] = pcl_ub1(r.top.x); t[2] = pcl_ub2(r.top.x);
+    t[3] = pcl_ub0(r.top.y); t[4] = pcl_ub1(r.top.y); t[5] = pcl_ub2(r.top.y);
+    t[6] = pcl_ub0(r.bot.x); t[7] = pcl_ub1(r.bot.x); t[8] = pcl_ub2(r.bot.x);
+    t[9] = pcl_ub0(r.bot.y); t[10] = pcl_ub1(r.bot.y); t[11] = pcl_ub2(r.bot.y);
+}
+__device__ __forceinline__ void pcl_unpack_taps(__amdgpu_buffer_rsrc_t tex, const PclTaps<PCL_PANO_F32>& r, float t[12])
+{
+    pcl_f4 t00 = pcl_texel(tex, r.voff, 0), t01 = pcl_texel(tex, r.voff + 16, 0);
+    pcl_f4 t10 = pcl_texel(tex, r.voff, r.row), t11 = pcl_texel(tex, r.voff + 16, r.row);
+    t[0] = t00.x; t[1] = t00.y; t[2] = t00.z; t[3] = t01.x; t[4] = t01.y; t[5] = t01.z;
+    t[6] = t10.x; t[7] = t10.y; t[8] = t10.z; t[9] = t11.x; t[10] = t11.y; t[11] = t11.z;
 }
 
-// Two points (packed in the .x/.y halves) against one pose.
-// acc: 0 sum||d||, 1 unused here (count goes to `count`, wave-uniform), 2-4 sum g, 5-7 sum p x g — each an f2 whose
-// halves are added at the end.
-template <bool GRAD, int FMT>
-__device__ __forceinline__ void pcl_point_pose2(f2 x, f2 y, f2 z, f2 cr, f2 cg, f2 cb, bool valid0, bool valid1,
-                                                const float* __restrict__ R, const float* __restrict__ t,
-                                                __amdgpu_buffer_rsrc_t tex, const PclDims& dm, f2* acc, int& count)
+// What the PROJECTION phase of one pose (two points, packed in .x/.y) hands to its SAMPLING phase.
+template <int FMT>
+struct PclProj {
+    f2 px, py, pz;        // camera-frame point
+    f2 rho2, rinv;        // px^2 + py^2 and 1/rho
+    f2 fx, fy;            // bilinear fractions
+    f2 mphi, mth;         // dix/dphi, diy/dtheta, zeroed where the +-0.99 clip is active (clamp backward)
+    PclTaps<FMT> ta, tb;  // gathers in flight (point .x, point .y)
+};
+
+// Phase A: q = x - t, p = R q, cloud2idx, clip, pixel + fractions, issue the gathers.
+template <int FMT>
+__device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __restrict__ R, const float* __restrict__ t,
+                                             __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
 {
     const float inv_pi = 0.31830988618379067154f;
     // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
     f2 qx = x - F2(t[0]), qy = y - F2(t[1]), qz = z - F2(t[2]);
-    f2 px = pcl_fma2(F2(R[2]), qz, pcl_fma2(F2(R[1]), qy, F2(R[0]) * qx));
-    f2 py = pcl_fma2(F2(R[5]), qz, pcl_fma2(F2(R[4]), qy, F2(R[3]) * qx));
-    f2 pz = pcl_fma2(F2(R[8]), qz, pcl_fma2(F2(R[7]), qy, F2(R[6]) * qx));
+    o.px = pcl_fma2(F2(R[2]), qz, pcl_fma2(F2(R[1]), qy, F2(R[0]) * qx));
+    o.py = pcl_fma2(F2(R[5]), qz, pcl_fma2(F2(R[4]), qy, F2(R[3]) * qx));
+    o.pz = pcl_fma2(F2(R[8]), qz, pcl_fma2(F2(R[7]), qy, F2(R[6]) * qx));
     // cloud2idx (utils.py:44-59): gx = 1 - (atan2(py, a) + pi)/pi = -phi/pi ; gy = 2 theta/pi - 1
-    f2 a = px + F2(1e-6f), b = pz + F2(1e-6f);
-    f2 rho2 = pcl_fma2(px, px, py * py);
+    f2 a = o.px + F2(1e-6f), b = o.pz + F2(1e-6f);
+    o.rho2 = pcl_fma2(o.px, o.px, o.py * o.py);
     // 1/rho; rho = 0 gives rho2 * rinv = 0 and a zero gradient through rho (norm backward is 0 at 0)
-    f2 rinv = {__builtin_amdgcn_rsqf(fmaxf(rho2.x, 1e-37f)), __builtin_amdgcn_rsqf(fmaxf(rho2.y, 1e-37f))};
-    f2 rho = rho2 * rinv;
-    f2 phi = pcl_atan2_2<true>(py, a);
+    o.rinv = (f2){__builtin_amdgcn_rsqf(fmaxf(o.rho2.x, 1e-37f)), __builtin_amdgcn_rsqf(fmaxf(o.rho2.y, 1e-37f))};
+    f2 rho = o.rho2 * o.rinv;
+    f2 phi = pcl_atan2_2<true>(o.py, a);
     f2 theta = pcl_atan2_2<false>(rho, b);
     f2 gx = phi * F2(-inv_pi);
     f2 gy = pcl_fma2(theta, F2(2.0f * inv_pi), F2(-1.0f));
@@ -127,12 +145,28 @@ __device__ __forceinline__ void pcl_point_pose2(f2 x, f2 y, f2 z, f2 cr, f2 cg, 
     f2 ix = pcl_fma2(gxc, F2(dm.half_w), F2(dm.off_x));
     f2 iy = pcl_fma2(gyc, F2(dm.half_h), F2(dm.off_y));
     // ix, iy > 0 inside the border, so truncation == floor and fract == ix - floor(ix)
-    int x0a = (int)ix.x, x0b = (int)ix.y, y0a = (int)iy.x, y0b = (int)iy.y;
-    f2 fx = {__builtin_amdgcn_fractf(ix.x), __builtin_amdgcn_fractf(ix.y)};
-    f2 fy = {__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
+    pcl_issue_taps(tex, (int)ix.x, (int)iy.x, dm.Wp, o.ta);
+    pcl_issue_taps(tex, (int)ix.y, (int)iy.y, dm.Wp, o.tb);
+    o.fx = (f2){__builtin_amdgcn_fractf(ix.x), __builtin_amdgcn_fractf(ix.y)};
+    o.fy = (f2){__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
+    // clamp backward passes the gradient on [-0.99, 0.99]: dL/dphi = -(W/2pi) <u, dc/dix>, dL/dtheta = (H/pi) <u, dc/diy>
+    // (the constants carry the 1/255 of RGBA8 levels)
+    o.mphi = (f2){gx.x == gxc.x ? dm.k_phi : 0.f, gx.y == gxc.y ? dm.k_phi : 0.f};
+    o.mth = (f2){gy.x == gyc.x ? dm.k_theta : 0.f, gy.y == gyc.y ? dm.k_theta : 0.f};
+}
+
+// Phase B: bilinear colour, mask, residual, gradient, accumulate.
+// acc: 0 sum||d||, 1 unused here (count goes to `count`, wave-uniform), 2-4 sum g, 5-7 sum p x g — each an f2 whose
+// halves are added at the end.
+template <bool GRAD, int FMT>
+__device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 ncg, f2 ncb, bool valid0, bool valid1,
+                                            unsigned long long vmask0, unsigned long long vmask1,
+                                            __amdgpu_buffer_rsrc_t tex, const PclDims& dm, f2* acc, int& count)
+{
+    const f2 px = o.px, py = o.py, pz = o.pz, fx = o.fx, fy = o.fy;
     float ta[12], tb[12];
-    pcl_fetch_taps<FMT>(tex, x0a, y0a, dm.Wp, ta);
-    pcl_fetch_taps<FMT>(tex, x0b, y0b, dm.Wp, tb);
+    pcl_unpack_taps(tex, o.ta, ta);
+    pcl_unpack_taps(tex, o.tb, tb);
     // bilinear: top/bottom rows, then vertical; both partial derivatives fall out of the same differences
     f2 c[3], dv[3], dtop[3], dbot[3];
 #pragma unroll
@@ -145,14 +179,18 @@ __device__ __forceinline__ void pcl_point_pose2(f2 x, f2 y, f2 z, f2 cr, f2 cg, 
         c[k] = pcl_fma2(fy, dv[k], top);
     }
     // mask: sampled colour not exactly (0,0,0)                               (omniloc.py:198, :347)
-    bool keep0 = valid0 && fmaxf(fmaxf(fabsf(c[0].x), fabsf(c[1].x)), fabsf(c[2].x)) > 0.f;
-    bool keep1 = valid1 && fmaxf(fmaxf(fabsf(c[0].y), fabsf(c[1].y)), fabsf(c[2].y)) > 0.f;
-    count += __builtin_popcountll(__ballot(keep0)) + __builtin_popcountll(__ballot(keep1));
+    float m0 = fmaxf(fmaxf(fabsf(c[0].x), fabsf(c[1].x)), fabsf(c[2].x));
+    float m1 = fmaxf(fmaxf(fabsf(c[0].y), fabsf(c[1].y)), fabsf(c[2].y));
+    bool keep0 = valid0 && m0 > 0.f, keep1 = valid1 && m1 > 0.f;
+    // the count is wave-uniform bookkeeping: popcount of the compare's lane mask on the scalar unit (FCMP_OGT = 2)
+    count += __builtin_popcountll(__builtin_amdgcn_fcmpf(m0, 0.f, 2) & vmask0) +
+             __builtin_popcountll(__builtin_amdgcn_fcmpf(m1, 0.f, 2) & vmask1);
+    // d = c - rgb; the packed cloud stores -rgb (pcl_cloud_pack), so this is one fma / add without a negation
     f2 d0, d1, d2;
     if (FMT == PCL_PANO_U8) {
-        d0 = pcl_fma2(c[0], F2(dm.c_scale), -cr); d1 = pcl_fma2(c[1], F2(dm.c_scale), -cg); d2 = pcl_fma2(c[2], F2(dm.c_scale), -cb);
+        d0 = pcl_fma2(c[0], F2(dm.c_scale), ncr); d1 = pcl_fma2(c[1], F2(dm.c_scale), ncg); d2 = pcl_fma2(c[2], F2(dm.c_scale), ncb);
     } else {
-        d0 = c[0] - cr; d1 = c[1] - cg; d2 = c[2] - cb;
+        d0 = c[0] + ncr; d1 = c[1] + ncg; d2 = c[2] + ncb;
     }
     f2 n2 = pcl_fma2(d0, d0, pcl_fma2(d1, d1, d2 * d2));
     // 1/||d|| for kept points, 0 otherwise (also 0 * huge = 0 at ||d|| = 0: norm backward is 0 there)
@@ -165,16 +203,13 @@ __device__ __forceinline__ void pcl_point_pose2(f2 x, f2 y, f2 z, f2 cr, f2 cg, 
         f2 dh2 = pcl_fma2(fy, dbot[2] - dtop[2], dtop[2]);
         f2 sx = pcl_fma2(u0, dh0, pcl_fma2(u1, dh1, u2 * dh2));
         f2 sy = pcl_fma2(u0, dv[0], pcl_fma2(u1, dv[1], u2 * dv[2]));
-        // through unnormalise + clip (clamp passes the gradient on [-0.99, 0.99]) to the angles:
-        // dL/dphi = -(W/2pi) sx, dL/dtheta = (H/pi) sy (constants carry the 1/255 of RGBA8 levels)
-        f2 dphi = sx * F2(dm.k_phi), dth = sy * F2(dm.k_theta);
-        dphi = (f2){gx.x == gxc.x ? dphi.x : 0.f, gx.y == gxc.y ? dphi.y : 0.f};
-        dth = (f2){gy.x == gyc.x ? dth.x : 0.f, gy.y == gyc.y ? dth.y : 0.f};
+        f2 dphi = sx * o.mphi, dth = sy * o.mth;                                  // dL/dphi, dL/dtheta
         // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
-        f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, rho2);
+        f2 a = px + F2(1e-6f), b = pz + F2(1e-6f), rho = o.rho2 * o.rinv;
+        f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, o.rho2);
         f2 ai = dphi * (f2){__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
         f2 bi = dth * (f2){__builtin_amdgcn_rcpf(s2.x), __builtin_amdgcn_rcpf(s2.y)};
-        f2 k = b * bi * rinv;                                                     // (dL/drho) / rho
+        f2 k = b * bi * o.rinv;                                                   // (dL/drho) / rho
         f2 g0 = pcl_fma2(k, px, -(py * ai));
         f2 g1 = pcl_fma2(k, py, a * ai);
         f2 g2 = -(rho * bi);
@@ -218,40 +253,50 @@ __global__ void __launch_bounds__(PCL_BLOCK, (OCC > 0 ? OCC : 1)) pcl_loss_kerne
     if (end > (int)a.n) end = (int)a.n;
     const int last = (int)a.n - 1;
 
-    // two points per lane: i0 = base + tid, i1 = base + 256 + tid; loads for step k+1 are issued before step k is
-    // evaluated so their L2 latency hides under ~500 VALU instructions
-    float nx[2][6];
-    {
-        int j0 = min(begin + (int)threadIdx.x, last), j1 = min(begin + PCL_BLOCK + (int)threadIdx.x, last);
+    // two points per lane: i0 = base + tid, i1 = base + 256 + tid.  The loop is unrolled by two with ping-pong register
+    // sets: the loads of step k+1 are issued before step k is evaluated (their L2 latency hides under ~450 VALU
+    // instructions) and no register copies are needed to rotate the buffers.
+    auto load_step = [&](int base, float (&dst)[2][6]) {
+        int j0 = min(base + (int)threadIdx.x, last), j1 = min(base + PCL_BLOCK + (int)threadIdx.x, last);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            nx[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
-            nx[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
+            dst[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
+            dst[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
         }
-    }
-    for (int base = begin; base < end; base += PCL_STEP) {
+    };
+    auto eval_step = [&](int base, const float (&src)[2][6]) {
         const int i0 = base + threadIdx.x, i1 = i0 + PCL_BLOCK;
         const bool valid0 = i0 < end, valid1 = i1 < end;
-        f2 x = {nx[0][0], nx[1][0]}, y = {nx[0][1], nx[1][1]}, z = {nx[0][2], nx[1][2]};
-        f2 cr = {nx[0][3], nx[1][3]}, cg = {nx[0][4], nx[1][4]}, cb = {nx[0][5], nx[1][5]};
-        if (base + PCL_STEP < end) {
-            int j0 = min(i0 + PCL_STEP, last), j1 = min(i1 + PCL_STEP, last);
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                nx[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
-                nx[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
-            }
-        }
+        const unsigned long long vmask0 = __builtin_amdgcn_ballot_w64(valid0), vmask1 = __builtin_amdgcn_ballot_w64(valid1);
+        f2 x = {src[0][0], src[1][0]}, y = {src[0][1], src[1][1]}, z = {src[0][2], src[1][2]};
+        f2 ncr = {src[0][3], src[1][3]}, ncg = {src[0][4], src[1][4]}, ncb = {src[0][5], src[1][5]};
+        // Projection and sampling phase per pose.  (Measured: projecting all poses of the group before sampling the
+        // first — gathers of pose g in flight under the projection of pose g+1 — changes nothing at 4 waves/SIMD and
+        // costs 30 VGPRs; the kernel is VALU-issue bound, not latency bound.)
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const PclPoseRec* __restrict__ pr = a.poses + (pose0 + g);
             bool ok0 = valid0, ok1 = valid1;
+            unsigned long long m0 = vmask0, m1 = vmask1;
             if (VIS) {
                 const uint8_t* vis = a.visible + (int64_t)(pose0 + g) * a.n;
                 ok0 = ok0 && vis[min(i0, last)] != 0;
                 ok1 = ok1 && vis[min(i1, last)] != 0;
+                m0 = __builtin_amdgcn_ballot_w64(ok0); m1 = __builtin_amdgcn_ballot_w64(ok1);
             }
-            pcl_point_pose2<GRAD, FMT>(x, y, z, cr, cg, cb, ok0, ok1, pr->R, pr->t, tex, a.dims, acc[g], count[g]);
+            PclProj<FMT> pj;
+            pcl_project2<FMT>(x, y, z, pr->R, pr->t, tex, a.dims, pj);
+            pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tex, a.dims, acc[g], count[g]);
+        }
+    };
+    float bufA[2][6], bufB[2][6];
+    load_step(begin, bufA);
+    for (int base = begin; base < end; base += 2 * PCL_STEP) {
+        load_step(base + PCL_STEP, bufB);              // clamped to the last point if past the end (evaluated as invalid)
+        eval_step(base, bufA);
+        if (base + PCL_STEP < end) {
+            load_step(base + 2 * PCL_STEP, bufA);
+            eval_step(base + PCL_STEP, bufB);
         }
     }
 

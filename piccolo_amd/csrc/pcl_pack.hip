@@ -1,5 +1,5 @@
 // pcl_pack.hip — one-time repacking of the reference's tensors into the layouts the loss kernel streams.
-//   cloud : row-major (N,3) xyz + (N,3) rgb  (localize.py:159-164)  -> 6 SoA planes, optionally re-ordered
+//   cloud : row-major (N,3) xyz + (N,3) rgb  (localize.py:159-164)  -> 6 SoA planes x,y,z,-r,-g,-b, optionally re-ordered
 //   pano  : (H,W,3) float image              (localize.py:167-170)  -> zero-bordered (H+2, W+2) RGBA float4
 #include "pcl_device.h"
 
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_cloud_pack_kernel(const float* 
     if (i < n) {
         int64_t j = order ? order[i] : i;
         v[0] = xyz[3 * j]; v[1] = xyz[3 * j + 1]; v[2] = xyz[3 * j + 2];
-        v[3] = rgb[3 * j]; v[4] = rgb[3 * j + 1]; v[5] = rgb[3 * j + 2];
+        v[3] = -rgb[3 * j]; v[4] = -rgb[3 * j + 1]; v[5] = -rgb[3 * j + 2];   // the loss needs c - rgb: store -rgb
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) cloud[k * stride + i] = v[k];
