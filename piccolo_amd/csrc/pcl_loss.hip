@@ -133,7 +133,9 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     f2 a = o.px + F2(1e-6f), b = o.pz + F2(1e-6f);
     o.rho2 = pcl_fma2(o.px, o.px, o.py * o.py);
     // 1/rho; rho = 0 gives rho2 * rinv = 0 and a zero gradient through rho (norm backward is 0 at 0)
-    o.rinv = (f2){__builtin_amdgcn_rsqf(fmaxf(o.rho2.x, 1e-37f)), __builtin_amdgcn_rsqf(fmaxf(o.rho2.y, 1e-37f))};
+    // (+1e-37: exact no-op for any normal rho2, keeps rsq finite at 0; one packed add instead of two v_max)
+    f2 rg = o.rho2 + F2(1e-37f);
+    o.rinv = (f2){__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
     f2 rho = o.rho2 * o.rinv;
     f2 phi = pcl_atan2_2<true>(o.py, a);
     f2 theta = pcl_atan2_2<false>(rho, b);
@@ -151,6 +153,8 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     o.fy = (f2){__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
     // clamp backward passes the gradient on [-0.99, 0.99]: dL/dphi = -(W/2pi) <u, dc/dix>, dL/dtheta = (H/pi) <u, dc/diy>
     // (the constants carry the 1/255 of RGBA8 levels)
+    // (a wave-uniform "no lane is clipped" fast path was tried: the extra basic block costs more in scheduling and
+    // registers than the four selects it saves — 155 vs 141 us at cfg 2)
     o.mphi = (f2){gx.x == gxc.x ? dm.k_phi : 0.f, gx.y == gxc.y ? dm.k_phi : 0.f};
     o.mth = (f2){gy.x == gyc.x ? dm.k_theta : 0.f, gy.y == gyc.y ? dm.k_theta : 0.f};
 }
@@ -194,16 +198,17 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
     }
     f2 n2 = pcl_fma2(d0, d0, pcl_fma2(d1, d1, d2 * d2));
     // 1/||d|| for kept points, 0 otherwise (also 0 * huge = 0 at ||d|| = 0: norm backward is 0 there)
-    f2 rn = {keep0 ? __builtin_amdgcn_rsqf(fmaxf(n2.x, 1e-37f)) : 0.f, keep1 ? __builtin_amdgcn_rsqf(fmaxf(n2.y, 1e-37f)) : 0.f};
+    f2 ng = n2 + F2(1e-37f);
+    f2 rn = {keep0 ? __builtin_amdgcn_rsqf(ng.x) : 0.f, keep1 ? __builtin_amdgcn_rsqf(ng.y) : 0.f};
     acc[0] = pcl_fma2(n2, rn, acc[0]);                                            // ||d|| = n2 * rsqrt(n2)
     if (GRAD) {
-        f2 u0 = d0 * rn, u1 = d1 * rn, u2 = d2 * rn;                             // d||d||/dc
+        // d||d||/dc = d / ||d||: the 1/||d|| is folded into the two angle factors instead of scaling d three times
         f2 dh0 = pcl_fma2(fy, dbot[0] - dtop[0], dtop[0]);                       // dc/dix
         f2 dh1 = pcl_fma2(fy, dbot[1] - dtop[1], dtop[1]);
         f2 dh2 = pcl_fma2(fy, dbot[2] - dtop[2], dtop[2]);
-        f2 sx = pcl_fma2(u0, dh0, pcl_fma2(u1, dh1, u2 * dh2));
-        f2 sy = pcl_fma2(u0, dv[0], pcl_fma2(u1, dv[1], u2 * dv[2]));
-        f2 dphi = sx * o.mphi, dth = sy * o.mth;                                  // dL/dphi, dL/dtheta
+        f2 sx = pcl_fma2(d0, dh0, pcl_fma2(d1, dh1, d2 * dh2));
+        f2 sy = pcl_fma2(d0, dv[0], pcl_fma2(d1, dv[1], d2 * dv[2]));
+        f2 dphi = sx * (o.mphi * rn), dth = sy * (o.mth * rn);                    // dL/dphi, dL/dtheta
         // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
         f2 a = px + F2(1e-6f), b = pz + F2(1e-6f), rho = o.rho2 * o.rinv;
         f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, o.rho2);
