@@ -6,7 +6,7 @@
 #   usage: bash profiles/collect.sh TAG [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---workload cfg2 --steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${*:---workload ${WORKLOAD:-cfg2} --steps 2 --warmup 1 --no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -53,6 +53,14 @@ def main(d):
                           "includes Infinity-Cache hits (memory-side request counters)"}
             json.dump(tr, open(os.path.join(out, "traffic_%s.json" % k.replace("<", "_").replace(">", "").replace(", ", "_")), "w"), indent=1)
             print("traffic", tr)
+            # bench.py reads profiles/traffic.json: {workload: {"hbm_bytes_per_launch": ...}}
+            wl = os.environ.get("WORKLOAD", "cfg2")
+            merged = {}
+            tj = os.path.join(out, "traffic.json")
+            if os.path.exists(tj):
+                merged = json.load(open(tj))
+            merged[wl] = tr
+            json.dump(merged, open(tj, "w"), indent=1)
 
 
 if __name__ == "__main__":
