@@ -103,13 +103,18 @@ int pcl_sampling_loss(const float *cloud, int64_t n, const void *pano, int pano_
 #define PCL_GD_RESULT_STRIDE 14
 
 typedef struct pcl_gd_hyper {
-    double lr;        /* cfg.lr        (omniloc.py:25)  */
-    double factor;    /* cfg.factor    (omniloc.py:28)  */
-    int32_t patience; /* cfg.patience  (omniloc.py:27)  */
-    int32_t mode;     /* PCL_GD_SEQUENTIAL | PCL_GD_BATCH */
+    double lr;          /* cfg.lr        (omniloc.py:25)  */
+    double factor;      /* cfg.factor    (omniloc.py:28)  */
+    int32_t patience;   /* cfg.patience  (omniloc.py:27)  */
+    int32_t mode;       /* PCL_GD_SEQUENTIAL | PCL_GD_BATCH */
+    int32_t depth_mask; /* 0 = reference behaviour; 1 = recompute the scatter-min depth mask (pcl_depth_mask) for the
+                           current poses before every loss pass (build-defined, cfg key `depth_mask`) */
+    float depth_tau;    /* visibility tolerance of the depth mask */
 } pcl_gd_hyper;
 
 size_t pcl_gd_state_bytes(int B);
+/* workspace of pcl_gd_run: the loss partials, plus z-buffers and byte masks when hyper->depth_mask is set */
+size_t pcl_gd_workspace_bytes(int64_t n, int B, int H, int W, const pcl_gd_hyper *hyper_host);
 int pcl_gd_init(void *state, const float *trans, const float *rot, int B, const pcl_gd_hyper *hyper_host, void *stream);
 int pcl_gd_run(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, void *state, int B, const float *box,
                const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
@@ -150,6 +155,13 @@ int pcl_scatter_min_unpack(const uint64_t *zbuf, int64_t n, int H, int W, float 
  * workspace: H*W uint64. */
 int pcl_make_pano(const float *xyz_cam, const float *rgb, int64_t n, int H, int W, float *image, uint64_t *workspace,
                   void *stream);
+/* Scatter-min depth mask on the PACKED cloud for B poses (build-defined, off by default in the loss):
+ * visible[b][i] = 1 iff point i (packed order) is within (1 + tau) of the nearest point that falls into the same
+ * make_pano pixel (utils.py:158-165) of an H x W panorama seen from pose b.  Feeds the `visible` argument of
+ * pcl_sampling_loss.  workspace: pcl_depth_workspace_bytes(B, H, W). */
+size_t pcl_depth_workspace_bytes(int B, int H, int W);
+int pcl_depth_mask(const float *cloud, int64_t n, const float *trans, const float *rot, int B, int H, int W, float tau,
+                   uint8_t *visible, void *workspace, size_t workspace_bytes, void *stream);
 /* p = R (x - t) for one pose: xyz [n][3] -> out [n][3] (feeds make_pano / scatter-min; localize.py:266-267). */
 int pcl_transform_cloud(const float *xyz, int64_t n, const float *trans, const float *rot, float *out, void *stream);
 

@@ -19,7 +19,8 @@ PANO_F32, PANO_U8 = 0, 1
 
 
 class GdHyper(_c.Structure):
-    _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32)]
+    _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32),
+                ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/piccolo_hip.h declares
@@ -36,6 +37,9 @@ SIGNATURES = {
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
     "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "pcl_gd_state_bytes": (_sz, [_int]),
+    "pcl_gd_workspace_bytes": (_sz, [_i64, _int, _int, _int, _c.POINTER(GdHyper)]),
+    "pcl_depth_workspace_bytes": (_sz, [_int, _int, _int]),
+    "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _sz, _vp]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),
     "pcl_gd_run": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _int, _vp, _c.POINTER(GdHyper), _int, _vp, _vp, _sz, _vp, _vp]),
     "pcl_timer_create": (_vp, [_int]),

@@ -1,0 +1,115 @@
+// pcl_depth.hip — the scatter-min depth mask of the north star, per candidate pose, on the PACKED cloud.
+//
+// Build-defined (the reference imports torch_scatter.scatter_min at utils.py:6 and never calls it; its loss has no
+// occlusion test): for every pose b, pixel = make_pano's pixel of p = R_b (x - t_b) at the panorama's resolution
+// (utils.py:158-165), zmin[b][pixel] = min over the points landing there of ||p||^2 (a scatter-min), and point i is
+// visible for pose b iff ||p_i||^2 <= zmin * (1 + tau)^2.  The byte mask feeds pcl_loss_kernel<.., VIS = true, ..>.
+// Off by default: with the mask off the loss is exactly the reference's.
+//
+// Two passes over the cloud per call, both projection + one 4-byte access per point-pose:
+//   z pass   : 32-bit atomicMin of the squared depth's bit pattern (>= 0, so it orders like the float).  Points are in
+//              Morton order, so a wave's atomics fall into a small pixel patch: they resolve in L2 (95 % hit), and most
+//              pixels receive 0-2 points at 1 point per 2 pixels, so there is little same-address serialisation
+//              to remove with LDS tiling.
+//   mark pass: re-project, compare with the z-buffer, write one byte per point-pose.
+#include "pcl_device.h"
+
+struct PclDepthArgs {
+    const float* cloud;
+    int64_t n, stride;
+    const PclPoseRec* poses;
+    int B, H, W;
+    float tol2;           // (1 + tau)^2
+    uint32_t* zbuf;       // [B][H*W]
+    uint8_t* visible;     // [B][n]
+};
+
+// make_pano's pixel (utils.py:158-165) from the fused kernel's own atan2, plus the squared depth
+__device__ __forceinline__ void pcl_depth_point(float x, float y, float z, const PclPoseRec* __restrict__ pr, int H, int W,
+                                                int& pix, float& d2)
+{
+    const float inv_pi = 0.31830988618379067154f;
+    float qx = x - pr->t[0], qy = y - pr->t[1], qz = z - pr->t[2];
+    float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+    float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+    float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
+    float rho2 = fmaf(px, px, py * py);
+    float rho = rho2 * __builtin_amdgcn_rsqf(rho2 + 1e-37f);
+    float gx = -pcl_atan2(py, px + 1e-6f) * inv_pi;                       // in [-1, 1]
+    float gy = fmaf(pcl_atan2_ypos(rho, pz + 1e-6f), 2.0f * inv_pi, -1.0f);
+    int col = (int)((gx + 1.0f) * 0.5f * (float)(W - 1));                 // trunc(((g + 1) / 2) * (res - 1))
+    int row = (int)((gy + 1.0f) * 0.5f * (float)(H - 1));
+    col = min(max(col, 0), W - 1);
+    row = min(max(row, 0), H - 1);
+    pix = row * W + col;
+    d2 = fmaf(pz, pz, rho2);
+}
+
+template <bool MARK>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_depth_kernel(PclDepthArgs a)
+{
+    // grid.x over points, grid.y over poses; pose record through scalar loads
+    const int b = blockIdx.y;
+    const PclPoseRec* __restrict__ pr = a.poses + b;
+    const int64_t hw = (int64_t)a.H * a.W;
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * PCL_BLOCK) {
+        int pix; float d2;
+        pcl_depth_point(a.cloud[i], a.cloud[a.stride + i], a.cloud[2 * a.stride + i], pr, a.H, a.W, pix, d2);
+        uint32_t* cell = a.zbuf + (int64_t)b * hw + pix;
+        if (MARK) a.visible[(int64_t)b * a.n + i] = d2 <= __uint_as_float(*cell) * a.tol2 ? 1 : 0;
+        else atomicMin(cell, __float_as_uint(d2));
+    }
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = v;
+}
+
+size_t pcl_depth_zbuf_bytes(int B, int H, int W) { return (size_t)B * (size_t)H * (size_t)W * sizeof(uint32_t); }
+
+// zbuf: pcl_depth_zbuf_bytes; visible: B * n bytes.  Used by pcl_depth_mask and by the GD loop (pcl_gd.hip).
+int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
+                          uint32_t* zbuf, uint8_t* visible, hipStream_t s)
+{
+    PclDepthArgs a;
+    a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
+    a.poses = poses; a.B = B; a.H = H; a.W = W;
+    a.tol2 = (1.0f + tau) * (1.0f + tau);
+    a.zbuf = zbuf; a.visible = visible;
+    int64_t cells = (int64_t)B * H * W;
+    hipLaunchKernelGGL(pcl_fill_u32_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, cells, 0x7f800000u);   // +inf
+    int64_t want = (n + PCL_BLOCK - 1) / PCL_BLOCK;
+    dim3 grid((unsigned)(want < 1024 ? want : 1024), (unsigned)B);
+    hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(pcl_depth_kernel<true>, grid, dim3(PCL_BLOCK), 0, s, a);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void pcl_depth_pose_setup_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int B, PclPoseRec* recs)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float p[6] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2], rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
+    pcl_write_pose_rec(&recs[b], p);
+}
+
+extern "C" size_t pcl_depth_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * sizeof(PclPoseRec) + pcl_depth_zbuf_bytes(B, H, W);
+}
+
+extern "C" int pcl_depth_mask(const float* cloud, int64_t n, const float* trans, const float* rot, int B, int H, int W, float tau,
+                              uint8_t* visible, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !trans || !rot || !visible || !workspace || n <= 0 || B <= 0 || B > 65535 || H <= 0 || W <= 0 || !(tau >= 0.f))
+        return PCL_EINVAL;
+    if (workspace_bytes < pcl_depth_workspace_bytes(B, H, W)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    PclPoseRec* recs = (PclPoseRec*)workspace;
+    uint32_t* zbuf = (uint32_t*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
+    hipLaunchKernelGGL(pcl_depth_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
+    return pcl_launch_depth_mask(cloud, n, recs, B, H, W, tau, zbuf, visible, s);
+}

@@ -11,6 +11,9 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
                     int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s);
 size_t pcl_partials_bytes(int64_t n, int B);
 int pcl_plan_nchunks(int64_t n, int B);
+size_t pcl_depth_zbuf_bytes(int B, int H, int W);
+int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
+                          uint32_t* zbuf, uint8_t* visible, hipStream_t s);
 
 // Deterministic second-stage sum of the per-chunk partials of pose `b` (fixed lane->chunk assignment, double).
 __device__ inline void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, double out[PCL_NACC])
@@ -192,6 +195,16 @@ __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, fl
 
 extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? (size_t)B * (sizeof(PclGdPose) + sizeof(PclPoseRec)) : 0; }
 
+static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t pcl_gd_workspace_bytes(int64_t n, int B, int H, int W, const pcl_gd_hyper* hyper_host)
+{
+    if (n <= 0 || B <= 0 || !hyper_host) return 0;
+    size_t bytes = gd_align(pcl_partials_bytes(n, B));
+    if (hyper_host->depth_mask) bytes += gd_align(pcl_depth_zbuf_bytes(B, H, W)) + gd_align((size_t)B * (size_t)n);
+    return bytes;
+}
+
 extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, int B, const pcl_gd_hyper* hyper_host, void* stream)
 {
     if (!state || !trans || !rot || !hyper_host || B <= 0) return PCL_EINVAL;
@@ -260,14 +273,25 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     if (!cloud || !pano || !state || !box || !hyper_host || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0 || num_iter < 0)
         return PCL_EINVAL;
     if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
-    if (workspace_bytes < pcl_partials_bytes(n, B)) return PCL_EWORKSPACE;
+    if (workspace_bytes < pcl_gd_workspace_bytes(n, B, H, W, hyper_host)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partials = (float*)workspace;
+    uint32_t* zbuf = nullptr;
+    uint8_t* visible = nullptr;
+    if (hyper_host->depth_mask) {
+        if (!(hyper_host->depth_tau >= 0.f) || B > 65535) return PCL_EINVAL;
+        zbuf = (uint32_t*)((char*)workspace + gd_align(pcl_partials_bytes(n, B)));
+        visible = (uint8_t*)zbuf + gd_align(pcl_depth_zbuf_bytes(B, H, W));
+    }
     const int nchunks = pcl_plan_nchunks(n, B);
     for (int it = 0; it < num_iter; it++) {
+        if (visible) {
+            int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, s);
+            if (rcd) return rcd;
+        }
         const bool timed = tm && tm->used < tm->capacity;
         if (timed) (void)hipEventRecord(tm->start[tm->used], s);
-        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, nullptr, partials, s);
+        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s);
         if (timed) (void)hipEventRecord(tm->stop[tm->used++], s);
         if (rc) return rc;
         hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, nchunks, B, gd_poses(state),

@@ -12,6 +12,8 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     localize.py:227 on numpy >= 2);
   * omniloc_batch also accepts a single candidate (the reference asserts num_input > 1, omniloc.py:208; the assert
     is kept because callers may rely on it, see `strict_reference_asserts`);
+  * two extra, optional cfg keys: depth_mask (default False = reference behaviour) multiplies the north star's
+    scatter-min visibility (csrc/pcl_depth.hip) into the loss mask, depth_tau is its tolerance;
   * cfg.visualize: the reference's frame capture is broken (`new_xyz` undefined, omniloc.py:61); here it returns
     an empty frame list as 4th element instead of raising NameError.
 """
@@ -80,7 +82,8 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     # the reference recomputes these three quantiles every iteration (omniloc.py:53-55); they are loop invariant
     box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
     gd = ops.GradientDescent(cloud, pano, input_trans[starting_point], input_rot[starting_point], box,
-                             lr=lr, patience=patience, factor=factor, batch_mode=False)
+                             lr=lr, patience=patience, factor=factor, batch_mode=False,
+                             depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
     gd.run(num_iter)
     res = gd.result()[0]
     R = _rot_matrix(res[3:6])
@@ -109,7 +112,7 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
     box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
     gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=lr, patience=patience, factor=factor,
-                             batch_mode=True)
+                             batch_mode=True, depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
     gd.run(num_iter)
     res = gd.result()                       # (B, 14) on the GPU
     k = torch.argmin(res[:, 12])            # loss_list.argmin() of the last forward

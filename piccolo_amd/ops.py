@@ -113,6 +113,19 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
+def depth_mask(cloud, trans, rot, resolution, tau=0.02):
+    """(B, n) uint8 GPU tensor in PACKED point order: scatter-min visibility of every point for every pose."""
+    lib = _lib.load()
+    trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
+    B, (H, W) = int(trans.shape[0]), (int(resolution[0]), int(resolution[1]))
+    vis = torch.empty(B, cloud.n, dtype=torch.uint8, device=trans.device)
+    nws = lib.pcl_depth_workspace_bytes(B, H, W)
+    ws = _bytes(nws)
+    _lib.check(lib.pcl_depth_mask(_ptr(cloud.data), cloud.n, _ptr(trans), _ptr(rot), B, H, W, float(tau), _ptr(vis), _ptr(ws), nws,
+                                  _stream()), "pcl_depth_mask")
+    return vis
+
+
 def quantile_box(xyz, q):
     """(6,) GPU tensor: x_lo, x_hi, y_lo, y_hi, z_lo, z_hi — utils.py:208-229 on the three columns."""
     lib = _lib.load()
@@ -126,15 +139,17 @@ def quantile_box(xyz, q):
 class GradientDescent:
     """On-device GD refinement of B candidates (Adam + ReduceLROnPlateau + clamp), pcl_gd_* of the C ABI."""
 
-    def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True):
+    def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True, depth_mask=False,
+                 depth_tau=0.02):
         lib = _lib.load()
         self.cloud, self.pano = cloud, pano
         trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
         self.B = int(trans.shape[0])
         self.box = _dev(box).reshape(6)
-        self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL)
+        self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL,
+                                  1 if depth_mask else 0, float(depth_tau))
         self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
-        self.ws_bytes = lib.pcl_loss_workspace_bytes(cloud.n, self.B)
+        self.ws_bytes = lib.pcl_gd_workspace_bytes(cloud.n, self.B, pano.H, pano.W, ctypes.byref(self.hyper))
         self.ws = _bytes(self.ws_bytes)
         _lib.check(lib.pcl_gd_init(_ptr(self.state), _ptr(trans), _ptr(rot), self.B, ctypes.byref(self.hyper), _stream()),
                    "pcl_gd_init")

@@ -465,3 +465,46 @@ def test_large_batch_and_odd_batch(ops, oracle):
         assert rel(out[:, 0], ref["loss"]) <= 1e-5 + 3.0 / n
         if grad:
             assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+
+
+def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
+    """The build-defined scatter-min depth mask (parity unpinned: no reference call site).  (1) The packed-cloud mask
+    equals the oracle's scatter-min + threshold up to pixel-boundary flips.  (2) With occluders in front of the walls
+    the mask actually hides points.  (3) cfg.depth_mask=True runs inside the on-device GD loop and still converges;
+    cfg.depth_mask=False is bit-identical to not passing the key."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    n, H, W, B, tau = 40_000, 128, 256, 3, 0.02
+    xyz, rgb = synth.box_room(n, 17)
+    # occluders: a second, smaller box inside the room hides part of the walls from any viewpoint
+    inner, inner_rgb = synth.box_room(n // 4, 18)
+    xyz = np.concatenate([xyz, inner * 0.25 + np.array([1.5, 1.0, 0.0], np.float32)]).astype(np.float32)
+    rgb = np.concatenate([rgb, inner_rgb]).astype(np.float32)
+    t_gt, ypr_gt = synth.gt_pose(17)
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=17, sigma_t=0.1, sigma_r=0.05)
+    cloud = ops.Cloud(T(xyz), T(rgb))
+    vis = ops.depth_mask(cloud, T(trans), T(rot), (H, W), tau=tau).cpu().numpy()
+    order = cloud.order.cpu().numpy()
+    assert vis.shape == (B, len(xyz))
+    for b in range(B):
+        cam = synth.transform_cloud(xyz, trans[b], rot[b])
+        zmin, _ = oracle.scatter_min_depth(cam, (H, W))
+        row, col = oracle.pano_pixels(cam, (H, W))
+        d = np.linalg.norm(cam.astype(np.float64), axis=1)
+        ref = d <= zmin[row.astype(np.int64) * W + col].astype(np.float64) * (1 + tau)
+        got = np.empty(len(xyz), bool)
+        got[order] = vis[b].astype(bool)                 # packed slot j holds original point order[j]
+        assert (got != ref).mean() <= 5e-3, (b, (got != ref).mean())
+        assert 0.05 < 1 - ref.mean() < 0.95              # the occluder really hides something
+    img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+    base = dict(lr=0.1, num_iter=60, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=B)
+    X, C, I = T(xyz), T(rgb), T(img)
+    r_off = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(**base), {})
+    r_off2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=False, **base), {})
+    r_on = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=True, depth_tau=tau, **base), {})
+    assert all(torch.equal(a, b) for a, b in zip(r_off, r_off2))
+    R_gt = synth.rot_from_ypr_np(ypr_gt)
+    e_on = synth.pose_errors(r_on[0].numpy(), r_on[1].numpy(), t_gt, R_gt)
+    e_off = synth.pose_errors(r_off[0].numpy(), r_off[1].numpy(), t_gt, R_gt)
+    assert e_on[0] < 0.05 and e_on[1] < 1.0, (e_on, e_off)
+    assert not torch.equal(r_on[0], r_off[0])            # the mask changed the objective
