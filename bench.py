@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timer-stride", type=int, default=10, help="HIP-event pair around every n-th loss-kernel launch")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("PCL_BENCH_STREAMS", "1")),
                     help="independent query images refined concurrently on this many HIP streams per GPU (measured: no gain, "
                          "2545 vs 2536 candidate-poses/s at 1 vs 2 streams; kept as a knob)")
@@ -126,24 +127,29 @@ def main():
             img0_host, start0_host = img.cpu().numpy(), (tr, ro)
         del cam, img
     results = torch.zeros(n_img, 16, device=dev)
-    timer = ops.KernelTimer(NUM_ITER * K)
+    # HIP-event pairs around every TIMER_STRIDE-th loss launch of the timed region (each pair costs a few us of GPU
+    # timeline; bracketing all 100 launches of a refinement slows cfg 1 by 2x and cfg 2 by ~2 %)
+    timer = ops.KernelTimer(NUM_ITER * K, stride=args.timer_stride)
     # Independent images go to separate HIP streams: one image's optimiser epilogue, kernel boundaries and the tail of
     # its loss kernel overlap with the other image's loss kernel (each GD loop is a strict launch-after-launch chain).
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
+    # one optimiser object per stream, re-initialised per image (no allocation, no host synchronisation inside the
+    # timed region: the winner is selected on the device)
+    gds = [ops.GradientDescent(cloud, panos[0], starts[0][0], starts[0][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
+                               batch_mode=batch_mode) for _ in streams]
+    cols = torch.tensor([0, 1, 2, 3, 4, 5, 12], device=dev)
+
     def refine(i, tm=None):
-        st = streams[i % len(streams)]
+        st, gd = streams[i % len(streams)], gds[i % len(streams)]
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
-            gd = ops.GradientDescent(cloud, panos[i], starts[i][0], starts[i][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
-                                     batch_mode=batch_mode)
+            gd.pano = panos[i]
+            gd.reset(starts[i][0], starts[i][1])
             gd.run(NUM_ITER, timer=tm)
             res = gd.result()
-            k = torch.argmin(res[:, 12])                       # winner = smallest loss of the last forward
-            results[i, :6] = res[k, :6]
-            results[i, 6] = res[k, 12]
-            for t in (gd.state, gd.ws, res):
-                t.record_stream(st)
+            k = torch.argmin(res[:, 12]).reshape(1)            # winner = smallest loss of the last forward
+            results[i, :7] = res.index_select(0, k)[0].index_select(0, cols)
 
     def join_streams():
         for st in streams:

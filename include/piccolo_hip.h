@@ -129,6 +129,7 @@ int pcl_gd_result(const void *state, int B, float *result, void *stream);
 void *pcl_timer_create(int capacity);
 void pcl_timer_destroy(void *timer);
 void pcl_timer_reset(void *timer);
+void pcl_timer_set_stride(void *timer, int stride); /* time only every stride-th launch of a run (default 1) */
 int pcl_timer_read(void *timer, double *total_ms_host, int *launches_host);
 
 /* ---- stand-alone ops of the path ---------------------------------------------------------------------------- */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "pcl_timer_create": (_vp, [_int]),
     "pcl_timer_destroy": (None, [_vp]),
     "pcl_timer_reset": (None, [_vp]),
+    "pcl_timer_set_stride": (None, [_vp, _int]),
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),

@@ -216,7 +216,7 @@ extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, in
 
 // ---- kernel timer: host-side pool of event pairs (include/piccolo_hip.h)
 struct PclTimer {
-    int capacity, used;
+    int capacity, used, stride;
     hipEvent_t* start;
     hipEvent_t* stop;
 };
@@ -225,7 +225,7 @@ extern "C" void* pcl_timer_create(int capacity)
 {
     if (capacity <= 0) return nullptr;
     PclTimer* t = new PclTimer;
-    t->capacity = capacity; t->used = 0;
+    t->capacity = capacity; t->used = 0; t->stride = 1;
     t->start = new hipEvent_t[capacity];
     t->stop = new hipEvent_t[capacity];
     for (int i = 0; i < capacity; i++) {
@@ -247,6 +247,8 @@ extern "C" void pcl_timer_destroy(void* timer)
 }
 
 extern "C" void pcl_timer_reset(void* timer) { if (timer) ((PclTimer*)timer)->used = 0; }
+
+extern "C" void pcl_timer_set_stride(void* timer, int stride) { if (timer && stride > 0) ((PclTimer*)timer)->stride = stride; }
 
 extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_host)
 {
@@ -289,7 +291,9 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, s);
             if (rcd) return rcd;
         }
-        const bool timed = tm && tm->used < tm->capacity;
+        // time every `stride`-th launch only: an event pair costs a few microseconds of GPU timeline, which would
+        // distort short kernels if it bracketed all of them
+        const bool timed = tm && tm->used < tm->capacity && (it % tm->stride) == 0;
         if (timed) (void)hipEventRecord(tm->start[tm->used], s);
         int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s);
         if (timed) (void)hipEventRecord(tm->stop[tm->used++], s);

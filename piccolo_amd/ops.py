@@ -163,6 +163,34 @@ class GradientDescent:
                    "pcl_gd_run")
         return hist
 
+    def run_graph(self, num_iter):
+        """Same as run(num_iter) but the 2 * num_iter launches are captured into one hipGraph and replayed: the host
+        enqueues one graph instead of 200 kernels per refinement (pcl_gd_run neither allocates nor synchronises, so it
+        is capture-safe).  The instantiated graph is cached per num_iter; replaying it continues from the current
+        state, exactly like calling run() again."""
+        cache = self.__dict__.setdefault("_graphs", {})
+        g = cache.get(num_iter)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=self.state.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    self.run(num_iter)
+            torch.cuda.current_stream().wait_stream(side)
+            cache[num_iter] = g
+            # capture does not execute: fall through to the first replay
+        g.replay()
+
+    def reset(self, trans, rot):
+        """Re-initialise the optimiser state for new starting poses (same cloud / panorama / B): lets one captured
+        graph serve many refinements."""
+        lib = _lib.load()
+        trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
+        assert trans.shape[0] == self.B
+        _lib.check(lib.pcl_gd_init(_ptr(self.state), _ptr(trans), _ptr(rot), self.B, ctypes.byref(self.hyper), _stream()),
+                   "pcl_gd_init")
+
     def result(self):
         """(B, 14): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr."""
         lib = _lib.load()
@@ -174,10 +202,11 @@ class GradientDescent:
 class KernelTimer:
     """HIP-event pairs around every fused loss+gradient launch of GradientDescent.run (measurement aid)."""
 
-    def __init__(self, capacity):
+    def __init__(self, capacity, stride=1):
         self.handle = ctypes.c_void_p(_lib.load().pcl_timer_create(int(capacity)))
         if not self.handle:
             raise _lib.PiccoloHipError("pcl_timer_create failed")
+        _lib.load().pcl_timer_set_stride(self.handle, int(stride))
 
     def reset(self):
         _lib.load().pcl_timer_reset(self.handle)

@@ -508,3 +508,26 @@ def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
     e_off = synth.pose_errors(r_off[0].numpy(), r_off[1].numpy(), t_gt, R_gt)
     assert e_on[0] < 0.05 and e_on[1] < 1.0, (e_on, e_off)
     assert not torch.equal(r_on[0], r_off[0])            # the mask changed the objective
+
+
+def test_gd_graph_replay_is_bit_identical(ops):
+    """pcl_gd_run captured into a hipGraph and replayed == the eager launch sequence, bit for bit (deterministic
+    two-stage reduction, no atomics on the path)."""
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
+    box = ops.quantile_box(T(g["xyz"]), cfg.out_of_room_quantile)
+
+    def make():
+        return ops.GradientDescent(cloud, pano, T(g["trans0"]), T(g["rot0"]), box, lr=cfg.lr, patience=cfg.patience,
+                                   factor=cfg.factor, batch_mode=True)
+    eager = make()
+    eager.run(40)
+    graph = make()
+    graph.run_graph(20)
+    graph.run_graph(20)            # second replay continues from the state the first one left
+    assert torch.equal(eager.result(), graph.result())
+    graph.reset(T(g["trans0"]), T(g["rot0"]))
+    graph.run_graph(20)
+    graph.run_graph(20)
+    assert torch.equal(eager.result(), graph.result())
