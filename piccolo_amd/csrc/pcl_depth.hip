@@ -12,6 +12,8 @@
 //              pixels receive 0-2 points at 1 point per 2 pixels, so there is little same-address serialisation
 //              to remove with LDS tiling.
 //   mark pass: re-project, compare with the z-buffer, write one byte per point-pose.
+#include <stdlib.h>
+
 #include "pcl_device.h"
 
 struct PclDepthArgs {
@@ -61,6 +63,73 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_depth_kernel(PclDepthArgs a)
     }
 }
 
+// LDS-tiled z pass.  A block takes PCL_ZT_PTS Morton-contiguous points of one pose: their pixels form a compact patch.
+// The patch's top-left corner is found with a block-wide min, the points inside a 64 x 128-pixel window at that corner
+// are resolved with LDS atomicMin (32 KB tile), and the tile is then flushed row by row: each wave issues its global
+// atomicMins on 64 CONSECUTIVE pixels (one 256-byte segment, the shape global atomics run fastest in) and only for
+// cells that received a point.  Points outside the window (sparse clouds, the wrap seam) go straight to the global
+// z-buffer.  Measured at cfg 2 (1M points, 32 poses, 32M point-poses): 616 us for the direct scatter, 276 us tiled
+// (the mark pass, same projection without atomics: 100 us).  The number of global atomics is the same (~one per
+// distinct pixel hit); what changes is their shape.
+template <int PCL_ZT_H, int PCL_ZT_W, int PCL_ZT_PTS>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_zpass_tiled_kernel(PclDepthArgs a)
+{
+    constexpr int PCL_ZT_PER_THREAD = PCL_ZT_PTS / PCL_BLOCK;
+    __shared__ uint32_t tile[PCL_ZT_H * PCL_ZT_W];
+    __shared__ int org[3];
+    const int b = blockIdx.y;
+    const PclPoseRec* __restrict__ pr = a.poses + b;
+    uint32_t* __restrict__ zb = a.zbuf + (int64_t)b * a.H * a.W;
+    const uint32_t INF = 0x7f800000u;
+    for (int i = threadIdx.x; i < PCL_ZT_H * PCL_ZT_W; i += PCL_BLOCK) tile[i] = INF;
+    if (threadIdx.x < 3) org[threadIdx.x] = 0;
+    __syncthreads();
+
+    int pix[PCL_ZT_PER_THREAD];
+    uint32_t key[PCL_ZT_PER_THREAD];
+    int rsum = 0, csum = 0, cnt = 0;
+    const int64_t base = (int64_t)blockIdx.x * PCL_ZT_PTS;
+#pragma unroll
+    for (int k = 0; k < PCL_ZT_PER_THREAD; k++) {
+        int64_t i = base + k * PCL_BLOCK + threadIdx.x;
+        pix[k] = -1;
+        key[k] = INF;
+        if (i < a.n) {
+            float d2;
+            pcl_depth_point(a.cloud[i], a.cloud[a.stride + i], a.cloud[2 * a.stride + i], pr, a.H, a.W, pix[k], d2);
+            key[k] = __float_as_uint(d2);
+            int r = pix[k] / a.W, c = pix[k] - r * a.W;
+            rsum += r; csum += c; cnt += 1;
+        }
+    }
+    // window centred on the block's mean pixel (a min-corner anchor is dragged away by a few outliers, e.g. when the
+    // chunk straddles two walls)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rsum += __shfl_xor(rsum, o, 64);
+        csum += __shfl_xor(csum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&org[0], rsum); atomicAdd(&org[1], csum); atomicAdd(&org[2], cnt); }
+    __syncthreads();
+    const int npts = max(org[2], 1);
+    const int r0 = org[0] / npts - PCL_ZT_H / 2, c0 = org[1] / npts - PCL_ZT_W / 2;
+#pragma unroll
+    for (int k = 0; k < PCL_ZT_PER_THREAD; k++) {
+        if (pix[k] < 0) continue;
+        int r = pix[k] / a.W, c = pix[k] - r * a.W;
+        unsigned tr = (unsigned)(r - r0), tc = (unsigned)(c - c0);
+        if (tr < PCL_ZT_H && tc < PCL_ZT_W) atomicMin(&tile[tr * PCL_ZT_W + tc], key[k]);
+        else atomicMin(&zb[pix[k]], key[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PCL_ZT_H * PCL_ZT_W; i += PCL_BLOCK) {
+        uint32_t v = tile[i];
+        int r = r0 + i / PCL_ZT_W, c = c0 + (i & (PCL_ZT_W - 1));
+        if (v != INF && r >= 0 && r < a.H && c >= 0 && c < a.W) atomicMin(&zb[(int64_t)r * a.W + c], v);
+    }
+}
+
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v)
 {
     for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = v;
@@ -81,7 +150,15 @@ int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses
     hipLaunchKernelGGL(pcl_fill_u32_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, cells, 0x7f800000u);   // +inf
     int64_t want = (n + PCL_BLOCK - 1) / PCL_BLOCK;
     dim3 grid((unsigned)(want < 1024 ? want : 1024), (unsigned)B);
-    hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a);
+    static const bool direct = getenv("PCL_ZPASS_DIRECT") != nullptr;       // A/B knob: the untiled scatter
+    if (direct) hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a);
+    else {
+        // 64 x 128 window, 2048 points per block: best of {32..128} x {64,128} x {1024..4096} at cfg 2 (276 us; 288-374 us
+        // for the others; the direct scatter takes 616 us)
+        constexpr int TH = 64, TW = 128, PTS = 2048;
+        hipLaunchKernelGGL((pcl_zpass_tiled_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)B),
+                           dim3(PCL_BLOCK), 0, s, a);
+    }
     hipLaunchKernelGGL(pcl_depth_kernel<true>, grid, dim3(PCL_BLOCK), 0, s, a);
     PCL_LAUNCH_CHECK();
     return 0;

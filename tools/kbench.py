@@ -26,7 +26,8 @@ img = synth.quantise_like_image_file(ops.make_pano(cam, C, (H, W)))
 pano = ops.Pano(img, fmt=fmt)
 tr, ro = synth.start_poses(t_gt, ypr_gt, B, 0)
 box = ops.quantile_box(X, 0.05)
-gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr), torch.from_numpy(ro), box, lr=0.1, patience=5, factor=0.8, batch_mode=batch)
+gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr), torch.from_numpy(ro), box, lr=0.1, patience=5, factor=0.8, batch_mode=batch,
+                         depth_mask=os.environ.get("KB_DEPTH", "0") == "1")
 gd.run(5)
 timer = ops.KernelTimer(iters)
 gd.run(iters, timer=timer)
