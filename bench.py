@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images-per-launch", type=int, default=0,
+                    help="query images whose candidates share one launch chain (0 = auto: 256 // B, at most --steps); "
+                         "they share the cloud, each candidate samples its own image's panorama")
     ap.add_argument("--timer-stride", type=int, default=10, help="HIP-event pair around every n-th loss-kernel launch")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("PCL_BENCH_STREAMS", "1")),
                     help="independent query images refined concurrently on this many HIP streams per GPU (measured: no gain, "
@@ -106,7 +109,7 @@ def main():
 
     N, H, W, B, batch_mode = WORKLOADS[args.workload]
     K, Wm = args.steps, args.warmup
-    n_img = K + Wm
+    n_img = K            # warm-up refinements re-run the timed images (their results are overwritten by the timed pass)
 
     # ---- untimed setup: synthetic room, one panorama per query image, everything packed and resident in HBM
     xyz, rgb = synth.box_room(N, seed=0)                      # the shared cloud, replicated on every rank
@@ -134,22 +137,44 @@ def main():
     # its loss kernel overlap with the other image's loss kernel (each GD loop is a strict launch-after-launch chain).
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
 
-    # one optimiser object per stream, re-initialised per image (no allocation, no host synchronisation inside the
-    # timed region: the winner is selected on the device)
-    gds = [ops.GradientDescent(cloud, panos[0], starts[0][0], starts[0][1], box, lr=LR, patience=PATIENCE, factor=FACTOR,
-                               batch_mode=batch_mode) for _ in streams]
+    # Images are refined in groups of `ipl`: the group's ipl * B candidates go through ONE chain of launches (shared
+    # cloud, per-candidate panorama pointer).  More poses per launch share each cloud chunk in L2 and amortise the
+    # per-block costs; the candidates stay independent (own Adam / scheduler state), so per-image results are the same.
+    ipl = args.images_per_launch if args.images_per_launch > 0 else max(1, 256 // B)
+    ipl = max(1, min(ipl, K))
+    timed_groups = [list(range(s0, min(s0 + ipl, n_img))) for s0 in range(0, n_img, ipl)]
+    # W untimed warm-up steps, as whole launch groups of the sizes the timed pass uses (at least W image refinements)
+    warm_groups, done = [], 0
+    while done < Wm:
+        g = timed_groups[len(warm_groups) % len(timed_groups)]
+        warm_groups.append(g)
+        done += len(g)
+    groups = warm_groups + timed_groups
+    gd_by_size, prepared = {}, []
+    for grp in groups:
+        m = len(grp)
+        if m not in gd_by_size:
+            gd_by_size[m] = ops.GradientDescent(cloud, panos[0], starts[0][0].repeat(m, 1), starts[0][1].repeat(m, 1), box, lr=LR,
+                                                patience=PATIENCE, factor=FACTOR, batch_mode=batch_mode)
+        tr = torch.cat([starts[i][0] for i in grp]).contiguous()
+        ro = torch.cat([starts[i][1] for i in grp]).contiguous()
+        table = torch.tensor([panos[i].data.data_ptr() for i in grp for _ in range(B)], dtype=torch.int64, device=dev)
+        prepared.append((grp, tr, ro, table))
     cols = torch.tensor([0, 1, 2, 3, 4, 5, 12], device=dev)
 
-    def refine(i, tm=None):
-        st, gd = streams[i % len(streams)], gds[i % len(streams)]
+    def refine(gi, tm=None):
+        grp, tr, ro, table = prepared[gi]
+        gd = gd_by_size[len(grp)]
+        st = streams[gi % len(streams)]
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
-            gd.pano = panos[i]
-            gd.reset(starts[i][0], starts[i][1])
+            gd.reset(tr, ro)
+            gd.set_pano_table(table)
             gd.run(NUM_ITER, timer=tm)
-            res = gd.result()
-            k = torch.argmin(res[:, 12]).reshape(1)            # winner = smallest loss of the last forward
-            results[i, :7] = res.index_select(0, k)[0].index_select(0, cols)
+            res = gd.result().reshape(len(grp), B, -1)
+            k = torch.argmin(res[:, :, 12], dim=1)             # per image: smallest loss of the last forward
+            win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]
+            results[grp[0]:grp[-1] + 1, :7] = win.index_select(1, cols)
 
     def join_streams():
         for st in streams:
@@ -159,15 +184,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for i in range(Wm):
-        refine(i)
+    n_warm_groups = len(warm_groups)
+    for gi in range(n_warm_groups):
+        refine(gi)
     join_streams()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(Wm, n_img):
-        refine(i, timer)
+    for gi in range(n_warm_groups, len(groups)):
+        refine(gi, timer)
     join_streams()
     if dist is not None:                                       # the path's only collective: gather the results
         gathered = torch.empty(world * n_img, 16, device=dev)
@@ -187,7 +213,7 @@ def main():
     # accuracy of this rank's images (localize.py:239-247 formulas)
     errs = []
     res_host = results.cpu().numpy()
-    for i in range(Wm, n_img):
+    for i in range(n_img):
         R = ops.rot_from_ypr(torch.from_numpy(res_host[i, 3:6]))[0].cpu().numpy()
         errs.append(synth.pose_errors(res_host[i, :3], R, gts[i][0], synth.rot_from_ypr_np(gts[i][1])))
     errs = np.array(errs)
@@ -195,8 +221,12 @@ def main():
     if rank == 0:
         value = B * K * world / elapsed
         per_launch_ms = kernel_ms / max(launches, 1)
-        alg_bytes = BYTES_PER_POINT_POSE * N * B
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        # a launch of group g evaluates len(g) images x B candidates; every run times the same number of launches
+        timed_per_run = len(range(0, NUM_ITER, max(1, args.timer_stride)))
+        total_bytes = sum(BYTES_PER_POINT_POSE * N * B * len(g) * timed_per_run for g in timed_groups)
+        assert launches == timed_per_run * len(timed_groups), (launches, timed_per_run, len(timed_groups))
+        alg_bytes = total_bytes / max(launches, 1)              # mean algorithmic bytes per timed launch
+        achieved = total_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
@@ -210,10 +240,11 @@ def main():
             "config": {"workload": "%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD iterations per query image"
                                    % (args.workload, N, W, H, B, NUM_ITER),
                        "images_per_gpu": K, "sharding": "query images round-robin over ranks, RCCL all_gather of results",
-                       "mode": "omniloc_batch" if batch_mode else "omniloc", "streams_per_gpu": len(streams)},
+                       "mode": "omniloc_batch" if batch_mode else "omniloc", "streams_per_gpu": len(streams),
+                       "images_per_launch": ipl},
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
-            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if B % 2 == 0 else 1, "RGBA8" if panos[0].fmt == _lib.PANO_U8 else "F32"), "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if (B * ipl) % 2 == 0 else 1, "RGBA8" if panos[0].fmt == _lib.PANO_U8 else "F32"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches_timed": launches},
         }

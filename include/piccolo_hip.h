@@ -120,6 +120,13 @@ int pcl_gd_run(const float *cloud, int64_t n, const void *pano, int pano_format,
                const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
                size_t workspace_bytes, void *timer, void *stream);
 int pcl_gd_result(const void *state, int B, float *result, void *stream);
+/* Several query images against one shared cloud in ONE launch chain (BASELINE cfg 4: independent panoramas, shared
+ * cloud): candidate b samples panos[b] (device array of B device addresses of packed panoramas; all the same H, W and
+ * texel format as the `pano` passed to pcl_gd_run, which stays the default for entries that are 0).  Call after
+ * pcl_gd_init (which resets every candidate to the default panorama); panos == NULL clears the table.  More poses per
+ * launch share each cloud chunk in L2 and amortise the per-block costs: at cfg 2, 4 images x 32 candidates per launch
+ * run at the efficiency of cfg 3. */
+int pcl_gd_set_panos(void *state, const uint64_t *panos, int B, void *stream);
 
 /* ---- kernel timer (measurement aid, HOST object) --------------------------------------------------------------
  * A pool of hipEvent pairs.  When a timer is passed to pcl_gd_run, every launch of the fused loss+gradient kernel is

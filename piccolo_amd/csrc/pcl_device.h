@@ -17,7 +17,9 @@ typedef int pcl_i4 __attribute__((ext_vector_type(4)));
 struct PclPoseRec {
     float R[9];
     float t[3];
-    float pad[4];
+    uint32_t pano_lo, pano_hi;   // this pose's panorama (device address) when poses of several query images share a
+                                 // launch; 0 = the launch's default panorama
+    float pad[2];
 };
 static_assert(sizeof(PclPoseRec) == 64, "pose record is one 64-byte scalar-load line");
 
@@ -86,7 +88,8 @@ __device__ inline void pcl_write_pose_rec(PclPoseRec* rec, const float p[6])
     pcl_rot_from_ypr(p[3], p[4], p[5], R);
     for (int k = 0; k < 9; k++) rec->R[k] = R[k];
     rec->t[0] = p[0]; rec->t[1] = p[1]; rec->t[2] = p[2];
-    rec->pad[0] = rec->pad[1] = rec->pad[2] = rec->pad[3] = 0.f;
+    rec->pano_lo = 0u; rec->pano_hi = 0u;
+    rec->pad[0] = rec->pad[1] = 0.f;
 }
 
 // Same R for the GD epilogue, which runs once per iteration on ONE lane per candidate: fp32 sincosf (<= 2 ulp, the
@@ -102,8 +105,7 @@ __device__ inline void pcl_write_pose_rec_fast(PclPoseRec* rec, const float p[6]
     rec->R[0] = (float)(dcy * dcp); rec->R[1] = (float)(dcy * dsp * dsr - dsy * dcr); rec->R[2] = (float)(dcy * dsp * dcr + dsy * dsr);
     rec->R[3] = (float)(dsy * dcp); rec->R[4] = (float)(dsy * dsp * dsr + dcy * dcr); rec->R[5] = (float)(dsy * dsp * dcr - dcy * dsr);
     rec->R[6] = (float)(-dsp);      rec->R[7] = (float)(dcp * dsr);                   rec->R[8] = (float)(dcp * dcr);
-    rec->t[0] = p[0]; rec->t[1] = p[1]; rec->t[2] = p[2];
-    rec->pad[0] = rec->pad[1] = rec->pad[2] = rec->pad[3] = 0.f;
+    rec->t[0] = p[0]; rec->t[1] = p[1]; rec->t[2] = p[2];      // (pano_lo / pano_hi are left as they are)
     sc[0] = sy; sc[1] = cy; sc[2] = sp; sc[3] = cp;
 }
 

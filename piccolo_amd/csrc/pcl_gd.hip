@@ -121,6 +121,7 @@ __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float*
     for (int k = 0; k < 6; k++) { g.fwd[k] = g.leaf[k]; g.m[k] = 0.f; g.v[k] = 0.f; }
     g.last_loss = 0.f; g.num_bad = 0; g.step = 0; g.pad = 0;
     g.beta1_pow = 1.0; g.beta2_pow = 1.0;
+    recs[b].pano_lo = 0u; recs[b].pano_hi = 0u; recs[b].pad[0] = recs[b].pad[1] = 0.f;
     pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
     st[b] = g;
 }
@@ -303,6 +304,24 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
                            loss_history ? loss_history + (int64_t)it * B : nullptr);
         PCL_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+__global__ void pcl_gd_set_panos_kernel(PclPoseRec* recs, const unsigned long long* __restrict__ panos, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    unsigned long long p = panos ? panos[b] : 0ull;
+    recs[b].pano_lo = (uint32_t)(p & 0xffffffffull);
+    recs[b].pano_hi = (uint32_t)(p >> 32);
+}
+
+extern "C" int pcl_gd_set_panos(void* state, const uint64_t* panos, int B, void* stream)
+{
+    if (!state || B <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_gd_set_panos_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_recs(state, B),
+                       (const unsigned long long*)panos, B);
+    PCL_LAUNCH_CHECK();
     return 0;
 }
 

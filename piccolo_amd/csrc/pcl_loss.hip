@@ -289,9 +289,16 @@ __global__ void __launch_bounds__(PCL_BLOCK, (OCC > 0 ? OCC : 1)) pcl_loss_kerne
                 ok1 = ok1 && vis[min(i1, last)] != 0;
                 m0 = __builtin_amdgcn_ballot_w64(ok0); m1 = __builtin_amdgcn_ballot_w64(ok1);
             }
+            // poses of several query images may share a launch: each pose record can name its own panorama
+            // (same size and texel format); scalar work only
+            __amdgpu_buffer_rsrc_t tg = tex;
+            if (pr->pano_lo | pr->pano_hi) {
+                const void* pp = (const void*)(((unsigned long long)pr->pano_hi << 32) | (unsigned long long)pr->pano_lo);
+                tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, FMT == PCL_PANO_U8 ? 4 : 16);
+            }
             PclProj<FMT> pj;
-            pcl_project2<FMT>(x, y, z, pr->R, pr->t, tex, a.dims, pj);
-            pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tex, a.dims, acc[g], count[g]);
+            pcl_project2<FMT>(x, y, z, pr->R, pr->t, tg, a.dims, pj);
+            pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tg, a.dims, acc[g], count[g]);
         }
     };
     float bufA[2][6], bufB[2][6];

@@ -191,6 +191,24 @@ class GradientDescent:
         _lib.check(lib.pcl_gd_init(_ptr(self.state), _ptr(trans), _ptr(rot), self.B, ctypes.byref(self.hyper), _stream()),
                    "pcl_gd_init")
 
+    def set_panos(self, panos):
+        """Candidate b samples panos[b] (a list of B Pano objects, all the size / texel format of self.pano): lets the
+        candidates of several query images share one launch chain.  Call after __init__ / reset()."""
+        lib = _lib.load()
+        assert len(panos) == self.B
+        for p in panos:
+            if (p.H, p.W, p.fmt) != (self.pano.H, self.pano.W, self.pano.fmt):
+                raise ValueError("all panoramas of a launch must share size and texel format")
+        self._panos = list(panos)                      # keep them alive
+        self.set_pano_table(torch.tensor([p.data.data_ptr() for p in panos], dtype=torch.int64, device=self.state.device))
+
+    def set_pano_table(self, table):
+        """Same with a ready-made device tensor of B packed-panorama addresses (int64); the caller keeps the Pano
+        objects alive.  No host work besides the launch."""
+        assert table.dtype == torch.int64 and table.numel() == self.B and table.is_cuda
+        _lib.check(_lib.load().pcl_gd_set_panos(_ptr(self.state), _ptr(table), self.B, _stream()), "pcl_gd_set_panos")
+        self._pano_table = table
+
     def result(self):
         """(B, 14): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr."""
         lib = _lib.load()

@@ -531,3 +531,36 @@ def test_gd_graph_replay_is_bit_identical(ops):
     graph.run_graph(20)
     graph.run_graph(20)
     assert torch.equal(eager.result(), graph.result())
+
+
+def test_multi_image_launch_equals_per_image_runs(ops, oracle):
+    """Candidates of several query images in one launch chain (shared cloud, per-candidate panorama pointer) give
+    exactly the per-image results: the candidates never interact and the chunking of the cloud is the same here."""
+    from piccolo_amd import synth
+    n, H, W, B, I = 4096, 64, 128, 4, 3
+    xyz, rgb = synth.box_room(n, 23)
+    cloud = ops.Cloud(T(xyz), T(rgb))
+    box = ops.quantile_box(T(xyz), 0.05)
+    panos, starts = [], []
+    for k in range(I):
+        t_gt, ypr_gt = synth.gt_pose(40 + k)
+        img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+        panos.append(ops.Pano(T(img)))
+        starts.append(synth.start_poses(t_gt, ypr_gt, B, seed=40 + k))
+    single = []
+    for k in range(I):
+        gd = ops.GradientDescent(cloud, panos[k], T(starts[k][0]), T(starts[k][1]), box, lr=0.1, patience=5, factor=0.8)
+        gd.run(25)
+        single.append(gd.result())
+    tr = np.concatenate([s[0] for s in starts])
+    ro = np.concatenate([s[1] for s in starts])
+    gd = ops.GradientDescent(cloud, panos[0], T(tr), T(ro), box, lr=0.1, patience=5, factor=0.8)
+    gd.set_panos([panos[k] for k in range(I) for _ in range(B)])
+    gd.run(25)
+    assert torch.equal(gd.result(), torch.cat(single))
+    # reset() returns every candidate to the default panorama
+    gd.reset(T(tr), T(ro))
+    gd.run(25)
+    assert torch.equal(gd.result()[:B], single[0]) and not torch.equal(gd.result()[B:], torch.cat(single[1:]))
+    with pytest.raises(ValueError):
+        gd.set_panos([ops.Pano(T(np.zeros((32, 64, 3), np.float32)))] * (I * B))
