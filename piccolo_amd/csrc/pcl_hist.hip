@@ -1,0 +1,165 @@
+// pcl_hist.hip — the second trimming stage of the initialisation (reference utils.py:510-588, color_utils.py:68-144)
+// for a BATCH of candidate poses, fused into three kernels:
+//   1. pcl_splat_poses_kernel : make_pano's z-buffered 3x3 splat (see pcl_ops.hip) for every candidate pose at once,
+//                               straight from the world-frame cloud (p = R (x - t) computed in the kernel);
+//   2. pcl_query_hist_kernel  : per image block, the normalised 8x8x8 colour histogram of the query image's non-black
+//                               pixels (candidate independent, once per image);
+//   3. pcl_hist_inter_kernel  : per (candidate, block): resolve the z-buffer to colours, histogram the pixels where both
+//                               the render and the query are non-black in LDS, intersect with the query histogram.
+// The reference renders one candidate at a time (argsort + nine index_put_ passes) and builds every histogram with a
+// dozen tensor ops; the rendered image is never materialised here.
+// Only the middle block rows h = 1 .. num_split_h - 2 are used (utils.py:556); block j <-> (h = 1 + j / nsw, w = j % nsw).
+#include "pcl_device.h"
+
+#define PCL_HBINS 512   // 8 x 8 x 8
+
+__device__ inline void pcl_pano_pixel_ref(float px, float py, float pz, int H, int W, int& row, int& col)
+{
+    // make_pano's pixel (utils.py:158-165) with the reference's operation order (same as pcl_ops.hip)
+    float gx, gy;
+    pcl_cloud2idx_point(px, py, pz, gx, gy);
+    float cx = (gx + 1.0f) / 2.0f * (float)(W - 1);
+    float cy = (gy + 1.0f) / 2.0f * (float)(H - 1);
+    col = min(max((int)cx, 0), W - 1);
+    row = min(max((int)cy, 0), H - 1);
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_splat_poses_kernel(const float* __restrict__ xyz, int64_t n,
+                                                                    const PclPoseRec* __restrict__ poses, int H, int W,
+                                                                    unsigned long long* __restrict__ zbuf)
+{
+    const PclPoseRec* __restrict__ pr = poses + blockIdx.y;
+    unsigned long long* __restrict__ zb = zbuf + (int64_t)blockIdx.y * H * W;
+    const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
+    const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) {
+        float qx = xyz[3 * i] - pr->t[0], qy = xyz[3 * i + 1] - pr->t[1], qz = xyz[3 * i + 2] - pr->t[2];
+        float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+        float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+        float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
+        int row, col;
+        pcl_pano_pixel_ref(px, py, pz, H, W, row, col);
+        float d = sqrtf(px * px + py * py + pz * pz);
+        unsigned long long base = ((unsigned long long)__float_as_uint(d) << 29) | (unsigned long long)(0x1fffffffu - (uint32_t)i);
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            int r = min(max(row + drow[p], 0), H - 1), c = min(max(col + dcol[p], 0), W - 1);
+            atomicMin(&zb[(int64_t)r * W + c], ((unsigned long long)(8 - p) << 60) | base);
+        }
+    }
+}
+
+__device__ inline int pcl_hist_code(float r, float g, float b)
+{
+    // value.long() // ceil(255 / 8) per channel, r + 8 g + 64 b (color_utils.py:86-95)
+    return ((int)r >> 5) + 8 * ((int)g >> 5) + 64 * ((int)b >> 5);
+}
+
+// MODE 0: query histogram (zbuf unused) -> qhist[blk][512] normalised, nimg[blk]
+// MODE 1: candidate histogram + intersection -> inter[cand][blk], nproj[cand][blk]
+template <int MODE>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ rgb,
+                                                             const float* __restrict__ img, int H, int W, int nsh, int nsw,
+                                                             float* __restrict__ qhist, int* __restrict__ nimg,
+                                                             float* __restrict__ inter, int* __restrict__ nproj)
+{
+    __shared__ unsigned int hist[PCL_HBINS];
+    __shared__ float red[PCL_BLOCK / PCL_WAVE];
+    const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x;
+    const int bh = H / nsh, bw = W / nsw;
+    const int h = 1 + blk / nsw, w = blk - (h - 1) * nsw;
+    for (int i = threadIdx.x; i < PCL_HBINS; i += PCL_BLOCK) hist[i] = 0u;
+    __syncthreads();
+    const unsigned long long* zb = MODE == 1 ? zbuf + (int64_t)cand * H * W : nullptr;
+    for (int idx = threadIdx.x; idx < bh * bw; idx += PCL_BLOCK) {
+        int r = h * bh + idx / bw, c = w * bw + idx % bw;
+        int64_t pix = (int64_t)r * W + c;
+        float q0 = img[3 * pix], q1 = img[3 * pix + 1], q2 = img[3 * pix + 2];
+        bool qm = !(q0 == 0.f && q1 == 0.f && q2 == 0.f);            // query pixel not black
+        if (MODE == 0) {
+            if (qm) atomicAdd(&hist[pcl_hist_code(q0 * 255.f, q1 * 255.f, q2 * 255.f)], 1u);
+        } else {
+            unsigned long long k = zb[pix];
+            if (qm && k != ~0ull) {
+                int64_t j = (int64_t)(0x1fffffffu - (uint32_t)(k & 0x1fffffffull));
+                float p0 = rgb[3 * j] * 255.f, p1 = rgb[3 * j + 1] * 255.f, p2 = rgb[3 * j + 2] * 255.f;   // image * 255
+                if (!(p0 == 0.f && p1 == 0.f && p2 == 0.f)) atomicAdd(&hist[pcl_hist_code(p0, p1, p2)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // total count, then (MODE 0) normalise / (MODE 1) intersect: two bins per thread
+    unsigned int c0 = hist[threadIdx.x], c1 = hist[threadIdx.x + PCL_BLOCK];
+    float s = pcl_wave_sum((float)(c0 + c1));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float total = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    if (MODE == 0) {
+        qhist[(int64_t)blk * PCL_HBINS + threadIdx.x] = (float)c0 / total;              // hist / hist.sum()
+        qhist[(int64_t)blk * PCL_HBINS + threadIdx.x + PCL_BLOCK] = (float)c1 / total;
+        if (threadIdx.x == 0) nimg[blk] = (int)total;
+    } else {
+        const float* qh = qhist + (int64_t)blk * PCL_HBINS;
+        float v = fminf((float)c0 / total, qh[threadIdx.x]) + fminf((float)c1 / total, qh[threadIdx.x + PCL_BLOCK]);
+        if (!(total > 0.f)) v = 0.f;
+        v = pcl_wave_sum(v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            inter[(int64_t)cand * nblk + blk] = red[0] + red[1] + red[2] + red[3];      // torch.min(h1, h2).sum()
+            nproj[(int64_t)cand * nblk + blk] = (int)total;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u64b_kernel(unsigned long long* p, int64_t n, unsigned long long v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = v;
+}
+
+__global__ void pcl_hist_pose_setup_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int B, PclPoseRec* recs)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float p[6] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2], rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
+    pcl_write_pose_rec(&recs[b], p);
+}
+
+static size_t hist_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw)
+{
+    if (ncand <= 0 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return 0;
+    return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * H * W * 8) +
+           hist_align((size_t)(nsh - 2) * nsw * PCL_HBINS * sizeof(float));
+}
+
+extern "C" int pcl_hist_trim_scores(const float* xyz, const float* rgb, int64_t n, const float* img_hwc, int H, int W,
+                                    const float* trans, const float* rot, int ncand, int nsh, int nsw, float* inter, int* nproj,
+                                    int* nimg, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!xyz || !rgb || !img_hwc || !trans || !rot || !inter || !nproj || !nimg || !workspace) return PCL_EINVAL;
+    if (n <= 0 || n > 0x1fffffffll || ncand <= 0 || ncand > 65535 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
+    if (H / nsh <= 0 || W / nsw <= 0) return PCL_EINVAL;
+    if (workspace_bytes < pcl_hist_trim_workspace_bytes(ncand, H, W, nsh, nsw)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    PclPoseRec* recs = (PclPoseRec*)ws;
+    ws += hist_align((size_t)ncand * sizeof(PclPoseRec));
+    unsigned long long* zbuf = (unsigned long long*)ws;
+    ws += hist_align((size_t)ncand * H * W * 8);
+    float* qhist = (float*)ws;
+    const int nblk = (nsh - 2) * nsw;
+    hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
+    hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
+    int64_t want = (n + PCL_BLOCK - 1) / PCL_BLOCK;
+    hipLaunchKernelGGL(pcl_splat_poses_kernel, dim3((unsigned)(want < 2048 ? want : 2048), (unsigned)ncand), dim3(PCL_BLOCK), 0, s,
+                       xyz, n, recs, H, W, zbuf);
+    hipLaunchKernelGGL(pcl_hist_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr, rgb, img_hwc, H,
+                       W, nsh, nsw, qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, zbuf, rgb, img_hwc, H, W, nsh, nsw, qhist,
+                       nimg, inter, nproj);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -113,6 +113,34 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
+def hist_trim_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w, batch=16):
+    """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
+    Candidates are processed `batch` at a time (one z-buffer of H*W*8 bytes each)."""
+    lib = _lib.load()
+    img, xyz, rgb = _dev(img), _dev(xyz), _dev(rgb)
+    trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
+    K, (H, W) = int(trans.shape[0]), (int(img.shape[0]), int(img.shape[1]))
+    nblk = (num_split_h - 2) * num_split_w
+    inter = torch.empty(K, nblk, dtype=F32, device=img.device)
+    nproj = torch.empty(K, nblk, dtype=torch.int32, device=img.device)
+    nimg = torch.empty(nblk, dtype=torch.int32, device=img.device)
+    nws = lib.pcl_hist_trim_workspace_bytes(min(batch, K), H, W, num_split_h, num_split_w)
+    if nws == 0:
+        raise ValueError("hist_trim_scores: need num_split_h >= 3 and blocks of at least one pixel")
+    ws = _bytes(nws)
+    for k0 in range(0, K, batch):
+        k1 = min(k0 + batch, K)
+        _lib.check(lib.pcl_hist_trim_scores(_ptr(xyz), _ptr(rgb), int(xyz.shape[0]), _ptr(img), H, W, _ptr(trans[k0:k1]),
+                                            _ptr(rot[k0:k1]), k1 - k0, num_split_h, num_split_w, _ptr(inter[k0:k1]),
+                                            _ptr(nproj[k0:k1]), _ptr(nimg), _ptr(ws), nws, _stream()), "pcl_hist_trim_scores")
+    # a block with no pixels zeroes the rest of its block row (the reference `break`s there, utils.py:568-571)
+    empty = (nproj == 0) | (nimg == 0).unsqueeze(0)
+    empty = empty.reshape(K, num_split_h - 2, num_split_w)
+    dead = torch.cumsum(empty.to(torch.int32), dim=2) > 0
+    inter = torch.where(dead, torch.zeros((), device=inter.device), torch.nan_to_num(inter.reshape(dead.shape), nan=0.0))
+    return inter.sum(dim=(1, 2)) / float(num_split_h * num_split_w)
+
+
 def depth_mask(cloud, trans, rot, resolution, tau=0.02):
     """(B, n) uint8 GPU tensor in PACKED point order: scatter-min visibility of every point for every pose."""
     lib = _lib.load()

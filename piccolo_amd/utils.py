@@ -101,52 +101,11 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     return trans[torch.div(min_inds, Rn, rounding_mode="floor")], rot[min_inds % Rn]
 
 
-def _block_histograms(img255, mask, num_split_h, num_split_w, bins=8):
-    """Per-block normalised colour histograms (8x8x8 bins, bin = value // ceil(255/8)) over the block rows the
-    reference uses (1 .. num_split_h-2, utils.py:556); returns (rows*num_split_w, 512) and per-block pixel counts."""
-    H, W, _ = img255.shape
-    bh, bw = H // num_split_h, W // num_split_w
-    bin_size = int(math.ceil(255 / bins))
-    q = (img255.long() // bin_size)
-    code = q[..., 0] + bins * q[..., 1] + bins * bins * q[..., 2]
-    rows = range(1, num_split_h - 1)
-    hists, counts = [], []
-    for h in rows:
-        for w in range(num_split_w):
-            m = mask[h * bh:(h + 1) * bh, w * bw:(w + 1) * bw]
-            c = code[h * bh:(h + 1) * bh, w * bw:(w + 1) * bw][m]
-            hist = torch.bincount(c, minlength=bins ** 3).float()
-            counts.append(int(m.sum()))
-            hists.append(hist / hist.sum())
-    return torch.stack(hists), counts
-
-
 def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h, num_split_w):
     """Second trimming stage (utils.py:510-588): render a panorama per candidate and rank candidates by the mean
-    block-wise colour-histogram intersection with the query image.  Panoramas come from the z-buffer kernel."""
-    dev = ops.device()
-    img255 = ops._dev(img) * 255
-    H, W, _ = img255.shape
-    img_mask = ~(img255 == 0).all(dim=2)
-    scores = torch.zeros(len(trans), device=dev)
-    n_blocks = num_split_h * num_split_w
-    for i in range(len(trans)):
-        cam = ops.transform_cloud(xyz, trans[i], rot[i])
-        proj = ops.make_pano(cam, rgb, (H, W))
-        proj_mask = ~(proj == 0).all(dim=2)
-        both = proj_mask & img_mask
-        h_proj, n_proj = _block_histograms(proj, both, num_split_h, num_split_w)
-        h_img, n_img = _block_histograms(img255, img_mask, num_split_h, num_split_w)
-        inter = torch.minimum(h_proj, h_img).sum(-1)
-        inter = torch.nan_to_num(inter, nan=0.0)
-        # the reference leaves a whole block row at 0 from the first empty block on (`break`, utils.py:569-571)
-        inter = inter.reshape(-1, num_split_w)
-        for r in range(inter.shape[0]):
-            for w in range(num_split_w):
-                if n_proj[r * num_split_w + w] == 0 or n_img[r * num_split_w + w] == 0:
-                    inter[r, w:] = 0.0
-                    break
-        scores[i] = inter.sum() / n_blocks
+    block-wise colour-histogram intersection with the query image.  All candidates go through three fused kernels
+    (csrc/pcl_hist.hip): batched z-buffer splat, query histograms, per-(candidate, block) LDS histogram + intersection."""
+    scores = ops.hist_trim_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w)
     order = torch.argsort(scores)[-num_input:].flip(0).to(trans.device)
     return trans[order], rot[order]
 

@@ -400,10 +400,56 @@ def g11_end_to_end():
          t_err=t_err, r_err=r_err, self_noise=np.array(band))
 
 
+# ----------------------------------------------------------------------------- G12
+def g12_trim_input_hist():
+    """Second trimming stage (utils.py:510-588) on a small scene: per-candidate histogram-intersection scores and the
+    selected candidates.  The scores are captured by re-running the reference's own loop body (make_pano + color_utils
+    histogram / histogram_intersection); the selection by calling the function itself."""
+    import color_utils as ref_color
+    xyz, rgb, img, t_gt, ypr_gt = small_scene(n=6000, H=64, W=128, seed=9, black_patch=True)
+    rng = np.random.default_rng(12)
+    K = 10
+    trans = (t_gt[None] + rng.normal(0, 0.6, size=(K, 3))).astype(np.float32)
+    rot = (ypr_gt[None] + rng.normal(0, 0.5, size=(K, 3))).astype(np.float32)
+    trans[0], rot[0] = t_gt, ypr_gt
+    X, C, I = torch.from_numpy(xyz), torch.from_numpy(rgb), torch.from_numpy(img)
+    nh, nw = 4, 4
+    sel_t, sel_r = ref_utils.trim_input_hist_secondary(I, X, C, torch.from_numpy(trans), torch.from_numpy(rot), 4, nh, nw)
+    # scores, block by block, with the reference's own primitives
+    img255 = I.clone() * 255
+    H, W, _ = img255.shape
+    img_mask = torch.zeros([H, W], dtype=torch.bool)
+    img_mask[torch.sum(img255 == 0, dim=2) != 3] = True
+    bh, bw = H // nh, W // nw
+    scores = np.zeros(K)
+    inter_all = np.zeros((K, nh * nw))
+    for i in range(K):
+        R = ref_utils.rot_from_ypr(torch.from_numpy(rot[i]))
+        cam = torch.transpose(torch.matmul(R, torch.transpose(X - torch.from_numpy(trans[i]), 0, 1)), 0, 1)
+        proj = ref_utils.make_pano(cam, C, resolution=(H, W), return_torch=True)
+        proj_mask = torch.zeros([H, W], dtype=torch.bool)
+        proj_mask[torch.sum(proj == 0, dim=2) != 3] = True
+        for h in range(1, nh - 1):
+            for w in range(nw):
+                block = torch.zeros([H, W], dtype=torch.bool)
+                block[h * bh:(h + 1) * bh, w * bw:(w + 1) * bw] = True
+                fm = proj_mask & img_mask & block
+                fim = img_mask & block
+                if fm.sum() == 0 or fim.sum() == 0:
+                    continue
+                ph = ref_color.histogram(proj, fm, [8, 8, 8])
+                ih = ref_color.histogram(img255, fim, [8, 8, 8])
+                inter_all[i, h * nw + w] = float(ref_color.histogram_intersection(ih, ph))
+        scores[i] = np.nan_to_num(inter_all[i]).sum() / (nh * nw)
+    save("g12_trim_input_hist.npz", xyz=xyz, rgb=rgb, img=img, trans=trans, rot=rot, scores=scores, inter=inter_all,
+         selected_trans=sel_t.numpy(), selected_rot=sel_r.numpy(), num_split=np.array([nh, nw]))
+    print("G12 scores", np.round(scores, 4))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

@@ -128,3 +128,26 @@ def test_omniloc_batch_images_equals_per_image_calls(oracle):
     multi = po.omniloc_batch_images(imgs, X, C, [t.clone() for t in trs], [r.clone() for r in ros], cfg)
     for a, b in zip(single, multi):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
+    """The fused histogram-trim kernels (csrc/pcl_hist.hip) against the oracle restatement (same nearest-wins rendering:
+    equal up to pixel-boundary flips) and against the reference's own scores (G12; its renders differ in the pixels
+    where index_put_'s duplicate-index choice is undefined)."""
+    from oracle import hist
+    from piccolo_amd import ops, utils
+    g = load_golden("g12_trim_input_hist.npz")
+    nh, nw = [int(v) for v in g["num_split"]]
+    dev = torch.device("cuda")
+    I, X, C = [torch.from_numpy(g[k]).to(dev) for k in ("img", "xyz", "rgb")]
+    tr, ro = torch.from_numpy(g["trans"]).to(dev), torch.from_numpy(g["rot"]).to(dev)
+    scores = ops.hist_trim_scores(I, X, C, tr, ro, nh, nw, batch=4).cpu().numpy()      # 10 candidates in batches of 4, 4, 2
+    ref, _ = hist.hist_scores(g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], nh, nw)
+    assert np.abs(scores - ref).max() <= 2e-3, np.abs(scores - ref).max()
+    assert np.abs(scores - g["scores"]).max() <= 1e-2
+    assert np.array_equal(np.argsort(scores)[::-1][:4], np.argsort(g["scores"])[::-1][:4])
+    tt, trr = utils.trim_input_hist_secondary(I, X, C, tr, ro, 4, nh, nw)
+    assert np.array_equal(tt.cpu().numpy(), g["selected_trans"]) and np.array_equal(trr.cpu().numpy(), g["selected_rot"])
+    # an all-black query image: every block is empty -> all scores 0 (no NaN)
+    z = ops.hist_trim_scores(torch.zeros_like(I), X, C, tr, ro, nh, nw).cpu().numpy()
+    assert (z == 0).all()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Wall time of the initialisation stage (make_input: candidate grid -> sampling-loss trim -> histogram trim) and of the
+refinement, per query image, on one GPU.   python tools/init_bench.py [n_points H W]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from piccolo_amd import omniloc as po  # noqa: E402
+from piccolo_amd import ops, synth, utils  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+dev = torch.device("cuda:0")
+xyz, rgb = synth.box_room(n, 0)
+X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+t_gt, ypr_gt = synth.gt_pose(3)
+img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
+init = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_roll=2 * np.pi, min_roll=0, z_prior=None,
+            sample_rate_for_init=None, trans_init_mode="quantile", x_max=None, x_min=None, y_max=None, y_min=None, z_max=None,
+            z_min=None, num_split_h=4, num_split_w=4, xy_only=False, num_trans=50, yaw_only=False, num_yaw=4, num_pitch=4,
+            num_roll=4, dataset="Stanford2D-3D-S")
+
+
+class Cfg:
+    lr, num_iter, patience, factor, out_of_room_quantile, num_input = 0.1, 100, 5, 0.8, 0.05, 32
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+for rep in range(3):
+    sync(); t0 = time.perf_counter()
+    rot = utils.generate_rot_points(init, device=dev)
+    trans = utils.generate_trans_points(X, init, device=dev)
+    sync(); t1 = time.perf_counter()
+    tt, tr = utils.trim_input_loss(img, X, C, trans, rot, 64)
+    sync(); t2 = time.perf_counter()
+    it, ir = utils.trim_input_hist_secondary(img, X, C, tt, tr, 32, 4, 4)
+    sync(); t3 = time.perf_counter()
+    res = po.omniloc_batch(img, X, C, it.clone(), ir.clone(), Cfg(), {})
+    sync(); t4 = time.perf_counter()
+    te, re = synth.pose_errors(res[0].numpy(), res[1].numpy(), t_gt, synth.rot_from_ypr_np(ypr_gt))
+    print("candidates %dx%d: grids %.1f ms | loss trim %.1f ms | hist trim %.1f ms | GD %.1f ms | t_err %.3f m r_err %.2f deg"
+          % (len(trans), len(rot), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, te, re))
