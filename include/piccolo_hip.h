@@ -164,13 +164,13 @@ int pcl_scatter_min_unpack(const uint64_t *zbuf, int64_t n, int H, int W, float 
 int pcl_make_pano(const float *xyz_cam, const float *rgb, int64_t n, int H, int W, float *image, uint64_t *workspace,
                   void *stream);
 /* Second trimming stage of the initialisation for a batch of candidate poses (utils.py:510-588 with
- * color_utils.py:68-144): render the world-frame cloud xyz/rgb [n][3] from every candidate (make_pano semantics at the
- * image's resolution), and per block j of the middle block rows (h = 1 + j / nsw in 1..nsh-2, w = j % nsw) intersect the
+ * color_utils.py:68-144): render the packed world-frame cloud (pcl_cloud_pack) from every candidate (make_pano semantics
+ * at the image's resolution; among points at exactly equal distance the larger PACKED index wins), and per block j of the middle block rows (h = 1 + j / nsw in 1..nsh-2, w = j % nsw) intersect the
  * normalised 8x8x8 colour histogram of the rendered pixels (both render and query non-black) with that of the query
  * image's non-black pixels.  inter [ncand][(nsh-2)*nsw], nproj [ncand][..] = pixels histogrammed, nimg [..] likewise
  * for the query.  The caller forms score = sum_j inter / (nsh*nsw) with the reference's empty-block rule. */
 size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw);
-int pcl_hist_trim_scores(const float *xyz, const float *rgb, int64_t n, const float *img_hwc, int H, int W, const float *trans,
+int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, int H, int W, const float *trans,
                          const float *rot, int ncand, int nsh, int nsw, float *inter, int32_t *nproj, int32_t *nimg,
                          void *workspace, size_t workspace_bytes, void *stream);
 /* Scatter-min depth mask on the PACKED cloud for B poses (build-defined, off by default in the loss):

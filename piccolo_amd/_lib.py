@@ -39,7 +39,7 @@ SIGNATURES = {
     "pcl_gd_state_bytes": (_sz, [_int]),
     "pcl_gd_workspace_bytes": (_sz, [_i64, _int, _int, _int, _c.POINTER(GdHyper)]),
     "pcl_hist_trim_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
-    "pcl_hist_trim_scores": (_int, [_vp, _vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_hist_trim_scores": (_int, [_vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcl_depth_workspace_bytes": (_sz, [_int, _int, _int]),
     "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _sz, _vp]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),

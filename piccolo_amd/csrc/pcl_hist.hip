@@ -1,7 +1,8 @@
 // pcl_hist.hip — the second trimming stage of the initialisation (reference utils.py:510-588, color_utils.py:68-144)
 // for a BATCH of candidate poses, fused into three kernels:
 //   1. pcl_splat_poses_kernel : make_pano's z-buffered 3x3 splat (see pcl_ops.hip) for every candidate pose at once,
-//                               straight from the world-frame cloud (p = R (x - t) computed in the kernel);
+//                               straight from the packed world-frame cloud (p = R (x - t) computed in the kernel), with
+//                               LDS-tiled atomicMin;
 //   2. pcl_query_hist_kernel  : per image block, the normalised 8x8x8 colour histogram of the query image's non-black
 //                               pixels (candidate independent, once per image);
 //   3. pcl_hist_inter_kernel  : per (candidate, block): resolve the z-buffer to colours, histogram the pixels where both
@@ -24,28 +25,73 @@ __device__ inline void pcl_pano_pixel_ref(float px, float py, float pz, int H, i
     row = min(max((int)cy, 0), H - 1);
 }
 
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_splat_poses_kernel(const float* __restrict__ xyz, int64_t n,
+// Batched splat over the PACKED (Morton-ordered) cloud, LDS-tiled like the depth mask's z pass (pcl_depth.hip): a block
+// takes PTS contiguous points of one candidate, resolves the 3x3 splats that fall inside a TH x TW-pixel window centred on
+// the block's mean pixel with 64-bit LDS atomicMin, then flushes the touched cells row by row (each wave's global
+// atomics on 64 consecutive pixels).  The priority key is make_pano's: latest pass, then nearest, then largest index
+// (pcl_ops.hip); the index is the PACKED slot, so the colour is looked up in the packed cloud's (negated) colour planes.
+template <int TH, int TW, int PTS>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_splat_poses_kernel(const float* __restrict__ cloud, int64_t n, int64_t stride,
                                                                     const PclPoseRec* __restrict__ poses, int H, int W,
                                                                     unsigned long long* __restrict__ zbuf)
 {
+    constexpr int PER_THREAD = PTS / PCL_BLOCK;
+    __shared__ unsigned long long tile[TH * TW];
+    __shared__ int org[3];
     const PclPoseRec* __restrict__ pr = poses + blockIdx.y;
     unsigned long long* __restrict__ zb = zbuf + (int64_t)blockIdx.y * H * W;
     const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
     const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
-    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) {
-        float qx = xyz[3 * i] - pr->t[0], qy = xyz[3 * i + 1] - pr->t[1], qz = xyz[3 * i + 2] - pr->t[2];
-        float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
-        float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
-        float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
-        int row, col;
-        pcl_pano_pixel_ref(px, py, pz, H, W, row, col);
-        float d = sqrtf(px * px + py * py + pz * pz);
-        unsigned long long base = ((unsigned long long)__float_as_uint(d) << 29) | (unsigned long long)(0x1fffffffu - (uint32_t)i);
+    for (int i = threadIdx.x; i < TH * TW; i += PCL_BLOCK) tile[i] = ~0ull;
+    if (threadIdx.x < 3) org[threadIdx.x] = 0;
+    __syncthreads();
+
+    int row[PER_THREAD], col[PER_THREAD];
+    unsigned long long base[PER_THREAD];
+    int rsum = 0, csum = 0, cnt = 0;
+    const int64_t first = (int64_t)blockIdx.x * PTS;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        int64_t i = first + k * PCL_BLOCK + threadIdx.x;
+        row[k] = -1;
+        if (i < n) {
+            float qx = cloud[i] - pr->t[0], qy = cloud[stride + i] - pr->t[1], qz = cloud[2 * stride + i] - pr->t[2];
+            float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+            float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+            float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
+            pcl_pano_pixel_ref(px, py, pz, H, W, row[k], col[k]);
+            float d = sqrtf(px * px + py * py + pz * pz);
+            base[k] = ((unsigned long long)__float_as_uint(d) << 29) | (unsigned long long)(0x1fffffffu - (uint32_t)i);
+            rsum += row[k]; csum += col[k]; cnt += 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rsum += __shfl_xor(rsum, o, 64);
+        csum += __shfl_xor(csum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&org[0], rsum); atomicAdd(&org[1], csum); atomicAdd(&org[2], cnt); }
+    __syncthreads();
+    const int npts = max(org[2], 1);
+    const int r0 = org[0] / npts - TH / 2, c0 = org[1] / npts - TW / 2;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        if (row[k] < 0) continue;
 #pragma unroll
         for (int p = 0; p < 9; p++) {
-            int r = min(max(row + drow[p], 0), H - 1), c = min(max(col + dcol[p], 0), W - 1);
-            atomicMin(&zb[(int64_t)r * W + c], ((unsigned long long)(8 - p) << 60) | base);
+            int r = min(max(row[k] + drow[p], 0), H - 1), c = min(max(col[k] + dcol[p], 0), W - 1);
+            unsigned long long key = ((unsigned long long)(8 - p) << 60) | base[k];
+            unsigned tr = (unsigned)(r - r0), tc = (unsigned)(c - c0);
+            if (tr < TH && tc < TW) atomicMin(&tile[tr * TW + tc], key);
+            else atomicMin(&zb[(int64_t)r * W + c], key);
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += PCL_BLOCK) {
+        unsigned long long v = tile[i];
+        int r = r0 + i / TW, c = c0 + i % TW;
+        if (v != ~0ull && r >= 0 && r < H && c >= 0 && c < W) atomicMin(&zb[(int64_t)r * W + c], v);
     }
 }
 
@@ -58,8 +104,8 @@ __device__ inline int pcl_hist_code(float r, float g, float b)
 // MODE 0: query histogram (zbuf unused) -> qhist[blk][512] normalised, nimg[blk]
 // MODE 1: candidate histogram + intersection -> inter[cand][blk], nproj[cand][blk]
 template <int MODE>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ rgb,
-                                                             const float* __restrict__ img, int H, int W, int nsh, int nsw,
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ cloud,
+                                                             int64_t stride, const float* __restrict__ img, int H, int W, int nsh, int nsw,
                                                              float* __restrict__ qhist, int* __restrict__ nimg,
                                                              float* __restrict__ inter, int* __restrict__ nproj)
 {
@@ -82,7 +128,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long
             unsigned long long k = zb[pix];
             if (qm && k != ~0ull) {
                 int64_t j = (int64_t)(0x1fffffffu - (uint32_t)(k & 0x1fffffffull));
-                float p0 = rgb[3 * j] * 255.f, p1 = rgb[3 * j + 1] * 255.f, p2 = rgb[3 * j + 2] * 255.f;   // image * 255
+                // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
+                float p0 = -cloud[3 * stride + j] * 255.f, p1 = -cloud[4 * stride + j] * 255.f, p2 = -cloud[5 * stride + j] * 255.f;
                 if (!(p0 == 0.f && p1 == 0.f && p2 == 0.f)) atomicAdd(&hist[pcl_hist_code(p0, p1, p2)], 1u);
             }
         }
@@ -135,11 +182,11 @@ extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh
            hist_align((size_t)(nsh - 2) * nsw * PCL_HBINS * sizeof(float));
 }
 
-extern "C" int pcl_hist_trim_scores(const float* xyz, const float* rgb, int64_t n, const float* img_hwc, int H, int W,
+extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* img_hwc, int H, int W,
                                     const float* trans, const float* rot, int ncand, int nsh, int nsw, float* inter, int* nproj,
                                     int* nimg, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!xyz || !rgb || !img_hwc || !trans || !rot || !inter || !nproj || !nimg || !workspace) return PCL_EINVAL;
+    if (!cloud || !img_hwc || !trans || !rot || !inter || !nproj || !nimg || !workspace) return PCL_EINVAL;
     if (n <= 0 || n > 0x1fffffffll || ncand <= 0 || ncand > 65535 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
     if (H / nsh <= 0 || W / nsw <= 0) return PCL_EINVAL;
     if (workspace_bytes < pcl_hist_trim_workspace_bytes(ncand, H, W, nsh, nsw)) return PCL_EWORKSPACE;
@@ -153,13 +200,14 @@ extern "C" int pcl_hist_trim_scores(const float* xyz, const float* rgb, int64_t 
     const int nblk = (nsh - 2) * nsw;
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
-    int64_t want = (n + PCL_BLOCK - 1) / PCL_BLOCK;
-    hipLaunchKernelGGL(pcl_splat_poses_kernel, dim3((unsigned)(want < 2048 ? want : 2048), (unsigned)ncand), dim3(PCL_BLOCK), 0, s,
-                       xyz, n, recs, H, W, zbuf);
-    hipLaunchKernelGGL(pcl_hist_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr, rgb, img_hwc, H,
-                       W, nsh, nsw, qhist, nimg, inter, nproj);
-    hipLaunchKernelGGL(pcl_hist_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, zbuf, rgb, img_hwc, H, W, nsh, nsw, qhist,
-                       nimg, inter, nproj);
+    const int64_t stride = pcl_cloud_stride(n);
+    constexpr int TH = 64, TW = 64, PTS = 2048;                   // 32 KB of 64-bit cells per block
+    hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
+                       dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
+    hipLaunchKernelGGL(pcl_hist_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr, cloud, stride,
+                       img_hwc, H, W, nsh, nsw, qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W, nsh, nsw,
+                       qhist, nimg, inter, nproj);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -113,11 +113,11 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
-def hist_trim_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w, batch=16):
+def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
-    Candidates are processed `batch` at a time (one z-buffer of H*W*8 bytes each)."""
+    `cloud` is a packed Cloud.  Candidates are processed `batch` at a time (one z-buffer of H*W*8 bytes each)."""
     lib = _lib.load()
-    img, xyz, rgb = _dev(img), _dev(xyz), _dev(rgb)
+    img = _dev(img)
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
     K, (H, W) = int(trans.shape[0]), (int(img.shape[0]), int(img.shape[1]))
     nblk = (num_split_h - 2) * num_split_w
@@ -130,7 +130,7 @@ def hist_trim_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w, batch=
     ws = _bytes(nws)
     for k0 in range(0, K, batch):
         k1 = min(k0 + batch, K)
-        _lib.check(lib.pcl_hist_trim_scores(_ptr(xyz), _ptr(rgb), int(xyz.shape[0]), _ptr(img), H, W, _ptr(trans[k0:k1]),
+        _lib.check(lib.pcl_hist_trim_scores(_ptr(cloud.data), cloud.n, _ptr(img), H, W, _ptr(trans[k0:k1]),
                                             _ptr(rot[k0:k1]), k1 - k0, num_split_h, num_split_w, _ptr(inter[k0:k1]),
                                             _ptr(nproj[k0:k1]), _ptr(nimg), _ptr(ws), nws, _stream()), "pcl_hist_trim_scores")
     # a block with no pixels zeroes the rest of its block row (the reference `break`s there, utils.py:568-571)

@@ -105,7 +105,7 @@ def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h,
     """Second trimming stage (utils.py:510-588): render a panorama per candidate and rank candidates by the mean
     block-wise colour-histogram intersection with the query image.  All candidates go through three fused kernels
     (csrc/pcl_hist.hip): batched z-buffer splat, query histograms, per-(candidate, block) LDS histogram + intersection."""
-    scores = ops.hist_trim_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w)
+    scores = ops.hist_trim_scores(img, packed_cloud(xyz, rgb), trans, rot, num_split_h, num_split_w)
     order = torch.argsort(scores)[-num_input:].flip(0).to(trans.device)
     return trans[order], rot[order]
 

@@ -141,7 +141,8 @@ def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
     dev = torch.device("cuda")
     I, X, C = [torch.from_numpy(g[k]).to(dev) for k in ("img", "xyz", "rgb")]
     tr, ro = torch.from_numpy(g["trans"]).to(dev), torch.from_numpy(g["rot"]).to(dev)
-    scores = ops.hist_trim_scores(I, X, C, tr, ro, nh, nw, batch=4).cpu().numpy()      # 10 candidates in batches of 4, 4, 2
+    cloud = ops.Cloud(X, C)
+    scores = ops.hist_trim_scores(I, cloud, tr, ro, nh, nw, batch=4).cpu().numpy()     # 10 candidates in batches of 4, 4, 2
     ref, _ = hist.hist_scores(g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], nh, nw)
     assert np.abs(scores - ref).max() <= 2e-3, np.abs(scores - ref).max()
     assert np.abs(scores - g["scores"]).max() <= 1e-2
@@ -149,5 +150,5 @@ def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
     tt, trr = utils.trim_input_hist_secondary(I, X, C, tr, ro, 4, nh, nw)
     assert np.array_equal(tt.cpu().numpy(), g["selected_trans"]) and np.array_equal(trr.cpu().numpy(), g["selected_rot"])
     # an all-black query image: every block is empty -> all scores 0 (no NaN)
-    z = ops.hist_trim_scores(torch.zeros_like(I), X, C, tr, ro, nh, nw).cpu().numpy()
+    z = ops.hist_trim_scores(torch.zeros_like(I), cloud, tr, ro, nh, nw).cpu().numpy()
     assert (z == 0).all()
