@@ -3,10 +3,10 @@
 //   1. pcl_splat_poses_kernel : make_pano's z-buffered 3x3 splat (see pcl_ops.hip) for every candidate pose at once,
 //                               straight from the packed world-frame cloud (p = R (x - t) computed in the kernel), with
 //                               LDS-tiled atomicMin;
-//   2. pcl_query_hist_kernel  : per image block, the normalised 8x8x8 colour histogram of the query image's non-black
-//                               pixels (candidate independent, once per image);
-//   3. pcl_hist_inter_kernel  : per (candidate, block): resolve the z-buffer to colours, histogram the pixels where both
-//                               the render and the query are non-black in LDS, intersect with the query histogram.
+//   2. pcl_hist_accum_kernel  : per (candidate, block, pixel range): resolve the z-buffer to colours and histogram the
+//                               pixels where both the render and the query are non-black in LDS (mode 0: the query image's
+//                               own non-black pixels), merged into global counters with integer atomics;
+//   3. pcl_hist_final_kernel  : normalise (query) / intersect with the query histogram (candidates).
 // The reference renders one candidate at a time (argsort + nine index_put_ passes) and builds every histogram with a
 // dozen tensor ops; the rendered image is never materialised here.
 // Only the middle block rows h = 1 .. num_split_h - 2 are used (utils.py:556); block j <-> (h = 1 + j / nsw, w = j % nsw).
@@ -101,23 +101,27 @@ __device__ inline int pcl_hist_code(float r, float g, float b)
     return ((int)r >> 5) + 8 * ((int)g >> 5) + 64 * ((int)b >> 5);
 }
 
-// MODE 0: query histogram (zbuf unused) -> qhist[blk][512] normalised, nimg[blk]
-// MODE 1: candidate histogram + intersection -> inter[cand][blk], nproj[cand][blk]
+// Histograms in two steps so that a handful of image blocks still fills the chip: every (block, candidate) is cut into
+// PCL_HSUB pixel ranges, each range is histogrammed in LDS by its own workgroup and its non-empty bins are added to a
+// global counter array (integer atomics: deterministic); a finalise kernel then normalises / intersects.
+#define PCL_HSUB 16
+
+// MODE 0: query image (zbuf unused, cand = 0)   MODE 1: candidate renders
 template <int MODE>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ cloud,
-                                                             int64_t stride, const float* __restrict__ img, int H, int W, int nsh, int nsw,
-                                                             float* __restrict__ qhist, int* __restrict__ nimg,
-                                                             float* __restrict__ inter, int* __restrict__ nproj)
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ cloud,
+                                                                   int64_t stride, const float* __restrict__ img, int H, int W, int nsh,
+                                                                   int nsw, unsigned int* __restrict__ ghist)
 {
     __shared__ unsigned int hist[PCL_HBINS];
-    __shared__ float red[PCL_BLOCK / PCL_WAVE];
-    const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x;
+    const int blk = blockIdx.x / PCL_HSUB, sub = blockIdx.x - blk * PCL_HSUB, cand = blockIdx.y, nblk = gridDim.x / PCL_HSUB;
     const int bh = H / nsh, bw = W / nsw;
     const int h = 1 + blk / nsw, w = blk - (h - 1) * nsw;
     for (int i = threadIdx.x; i < PCL_HBINS; i += PCL_BLOCK) hist[i] = 0u;
     __syncthreads();
     const unsigned long long* zb = MODE == 1 ? zbuf + (int64_t)cand * H * W : nullptr;
-    for (int idx = threadIdx.x; idx < bh * bw; idx += PCL_BLOCK) {
+    const int total = bh * bw, per = (total + PCL_HSUB - 1) / PCL_HSUB;
+    const int lo = sub * per, hi = min(lo + per, total);
+    for (int idx = lo + threadIdx.x; idx < hi; idx += PCL_BLOCK) {
         int r = h * bh + idx / bw, c = w * bw + idx % bw;
         int64_t pix = (int64_t)r * W + c;
         float q0 = img[3 * pix], q1 = img[3 * pix + 1], q2 = img[3 * pix + 2];
@@ -135,8 +139,21 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_kernel(const unsigned long
         }
     }
     __syncthreads();
-    // total count, then (MODE 0) normalise / (MODE 1) intersect: two bins per thread
-    unsigned int c0 = hist[threadIdx.x], c1 = hist[threadIdx.x + PCL_BLOCK];
+    unsigned int* g = ghist + ((int64_t)cand * nblk + blk) * PCL_HBINS;
+    for (int i = threadIdx.x; i < PCL_HBINS; i += PCL_BLOCK)
+        if (hist[i]) atomicAdd(&g[i], hist[i]);
+}
+
+// MODE 0: qhist[blk][512] = hist / hist.sum(), nimg[blk].   MODE 1: inter[cand][blk] = sum min(h / h.sum(), qhist), nproj.
+template <int MODE>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_final_kernel(const unsigned int* __restrict__ ghist, float* __restrict__ qhist,
+                                                                   int* __restrict__ nimg, float* __restrict__ inter,
+                                                                   int* __restrict__ nproj)
+{
+    __shared__ float red[PCL_BLOCK / PCL_WAVE];
+    const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x;
+    const unsigned int* g = ghist + ((int64_t)cand * nblk + blk) * PCL_HBINS;
+    unsigned int c0 = g[threadIdx.x], c1 = g[threadIdx.x + PCL_BLOCK];
     float s = pcl_wave_sum((float)(c0 + c1));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -178,8 +195,9 @@ static size_t hist_align(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw)
 {
     if (ncand <= 0 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return 0;
+    const size_t nblk = (size_t)(nsh - 2) * nsw;
     return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * H * W * 8) +
-           hist_align((size_t)(nsh - 2) * nsw * PCL_HBINS * sizeof(float));
+           hist_align(nblk * PCL_HBINS * sizeof(float)) + hist_align((size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int));
 }
 
 extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* img_hwc, int H, int W,
@@ -198,16 +216,22 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     ws += hist_align((size_t)ncand * H * W * 8);
     float* qhist = (float*)ws;
     const int nblk = (nsh - 2) * nsw;
+    ws += hist_align((size_t)nblk * PCL_HBINS * sizeof(float));
+    unsigned int* ghist_q = (unsigned int*)ws;                       // [nblk][512], then [ncand][nblk][512]
+    unsigned int* ghist_c = ghist_q + (size_t)nblk * PCL_HBINS;
+    (void)hipMemsetAsync(ghist_q, 0, (size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int), s);
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
     const int64_t stride = pcl_cloud_stride(n);
     constexpr int TH = 64, TW = 64, PTS = 2048;                   // 32 KB of 64-bit cells per block
     hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
                        dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
-    hipLaunchKernelGGL(pcl_hist_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr, cloud, stride,
-                       img_hwc, H, W, nsh, nsw, qhist, nimg, inter, nproj);
-    hipLaunchKernelGGL(pcl_hist_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W, nsh, nsw,
-                       qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
+                       cloud, stride, img_hwc, H, W, nsh, nsw, ghist_q);
+    hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W,
+                       nsh, nsw, ghist_c);
+    hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj);
     PCL_LAUNCH_CHECK();
     return 0;
 }
