@@ -30,6 +30,7 @@ WORKLOADS = {
     "cfg1": (100_000, 256, 512, 1, False),
     "cfg2": (1_000_000, 1024, 2048, 32, True),
     "cfg3": (1_000_000, 1024, 2048, 256, True),
+    "cfg4": (1_000_000, 1024, 2048, 32, True),      # 64 query images in all, sharded over the ranks (steps = 64 / world)
     "cfg5": (10_000_000, 2048, 4096, 32, True),
 }
 NUM_ITER, LR, PATIENCE, FACTOR, QUANTILE = 100, 0.1, 5, 0.8, 0.05
@@ -108,6 +109,8 @@ def main():
     _lib.load()
 
     N, H, W, B, batch_mode = WORKLOADS[args.workload]
+    if args.workload == "cfg4":
+        args.steps = max(1, 64 // world)
     K, Wm = args.steps, args.warmup
     n_img = K            # warm-up refinements re-run the timed images (their results are overwritten by the timed pass)
 
