@@ -6,14 +6,14 @@
 #   usage: bash profiles/collect.sh TAG [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:---workload ${WORKLOAD:-cfg2} --steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${*:---workload ${WORKLOAD:-cfg2} --steps 8 --warmup 8 --no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== kernel trace ($ARGS)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py $ARGS > $OUT/kt.log 2>&1
 tail -2 $OUT/kt.log
-PMC_ARGS="--workload ${WORKLOAD:-cfg2} --steps 1 --warmup 0 --no-cpu-baseline"
+PMC_ARGS="--workload ${WORKLOAD:-cfg2} --steps ${PMC_STEPS:-8} --warmup 0 --no-cpu-baseline"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
