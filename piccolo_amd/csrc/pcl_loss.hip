@@ -225,9 +225,10 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
     }
 }
 
-// OCC = minimum resident 256-thread blocks per CU the register allocator must allow (0: compiler's choice)
-template <int G, bool GRAD, bool VIS, int OCC, int FMT>
-__global__ void __launch_bounds__(PCL_BLOCK, (OCC > 0 ? OCC : 1)) pcl_loss_kernel(PclLossArgs a)
+// G poses per block, GRAD: with gradient, VIS: byte visibility mask, FMT: texel format.
+// (Forcing more resident blocks per CU through __launch_bounds__ was tried: the register allocator spills, 2-4x slower.)
+template <int G, bool GRAD, bool VIS, int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
 {
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.
     // Give every XCD a contiguous range of CHUNKS (a compact part of the room, hence of the panorama for all the
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(PCL_BLOCK, (OCC > 0 ? OCC : 1)) pcl_loss_kerne
 // ------------------------------------------------------------------------------------------------------------
 // launch planning (shared with the GD loop)
 
-// experiment knobs (read once): PCL_G = poses per block (1/2/4), PCL_OCC = launch-bounds variant, PCL_BLOCKS = target grid
+// tuning knobs for tools/kbench.py (read once per process): PCL_G = poses per block (1/2/4), PCL_BLOCKS = target grid size
 static int pcl_env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
@@ -380,25 +381,16 @@ size_t pcl_partials_bytes(int64_t n, int B)
 
 int pcl_plan_nchunks(int64_t n, int B) { return pcl_plan(n, B).nchunks; }
 
-template <int G, int OCC, int FMT>
-static void pcl_launch_go(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
-{
-    if (grad) {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, true, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, false, OCC, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-    } else {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, true, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, false, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-    }
-}
-
 template <int G, int FMT>
 static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
 {
-    static const int occ = pcl_env_int("PCL_OCC", 0);
-    if (occ == 4) pcl_launch_go<G, 4, FMT>(a, nblk, grad, vis, s);
-    else if (occ == 3) pcl_launch_go<G, 3, FMT>(a, nblk, grad, vis, s);
-    else pcl_launch_go<G, 0, FMT>(a, nblk, grad, vis, s);
+    if (grad) {
+        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, true, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, false, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+    } else {
+        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, true, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, false, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+    }
 }
 
 template <int FMT>

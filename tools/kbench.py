@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the fused loss+gradient kernel alone (HIP events around each launch) for one workload; tuning knobs come from
-the environment (PCL_G, PCL_OCC, PCL_BLOCKS — read by the library once per process).
+the environment (PCL_G, PCL_BLOCKS — read by the library once per process).
    python tools/kbench.py cfg2 [iters]"""
 import os
 import sys
@@ -33,6 +33,6 @@ timer = ops.KernelTimer(iters)
 gd.run(iters, timer=timer)
 ms, n = timer.read()
 per = ms / n
-print("%s G=%s OCC=%s BLOCKS=%s sort=%d fmt=%s : %.1f us/launch  %.1f G point-pose/s  roofline %.3f  loss %.5f" % (
-    wl, os.environ.get("PCL_G", "-"), os.environ.get("PCL_OCC", "-"), os.environ.get("PCL_BLOCKS", "-"), sort, fmt, per * 1e3,
+print("%s G=%s BLOCKS=%s sort=%d fmt=%s : %.1f us/launch  %.1f G point-pose/s  roofline %.3f  loss %.5f" % (
+    wl, os.environ.get("PCL_G", "-"), os.environ.get("PCL_BLOCKS", "-"), sort, fmt, per * 1e3,
     N * B / per / 1e6, 24.0 * N * B / (per * 1e-3) / 8e12, float(gd.result()[:, 12].min())))
