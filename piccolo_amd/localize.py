@@ -12,7 +12,7 @@ import torch
 
 from . import dist as pdist
 from . import ops, synth
-from .omniloc import omniloc, omniloc_batch
+from .omniloc import omniloc_all, omniloc_batch
 
 
 def refine_image(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=None):
@@ -22,7 +22,8 @@ def refine_image(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=No
     if getattr(cfg, "parallel", False):
         results = [omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, summaries)]
     else:
-        results = [omniloc(img, xyz, rgb, input_trans, input_rot, i, cfg, summaries) for i in range(input_trans.shape[0])]
+        # the reference loops omniloc() over the starting points (localize.py:219-220); same results, one launch chain
+        results = omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, summaries)
     best = min(range(len(results)), key=lambda i: float(results[i][2]))
     return results[best][0], results[best][1], results[best][2]
 

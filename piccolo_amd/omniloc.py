@@ -97,6 +97,28 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     return ret
 
 
+def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=None):
+    """Throughput extension: what the reference's non-parallel branch computes with
+    `for i in range(num_input): omniloc(..., i, ...)` (localize.py:219-220), for ALL starting points in one launch chain.
+    Every starting point keeps omniloc's SEQUENTIAL semantics (its own Adam / scheduler, clamp applied to the parameters
+    the next forward reads) and the points never interact, so the list returned equals the K separate calls."""
+    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
+    out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
+    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
+                             factor=_cfg(cfg, "factor", 0.9), batch_mode=False, depth_mask=_cfg(cfg, "depth_mask", False),
+                             depth_tau=_cfg(cfg, "depth_tau", 0.02))
+    gd.run(_cfg(cfg, "num_iter", 100))
+    res = gd.result()
+    K = res.shape[0]
+    R = ops.rot_from_ypr(res[:, 3:6])
+    host = torch.cat([res[:, 0:3], R.reshape(K, 9), res[:, 12:13]], dim=1).cpu()
+    with torch.no_grad():
+        input_trans.copy_(res[:, 6:9].to(input_trans.device))
+        input_rot.copy_(res[:, 9:12].to(input_rot.device))
+    return [[host[i, 0:3].reshape(3, 1).clone(), host[i, 3:12].reshape(3, 3).clone(), host[i, 12].clone()] for i in range(K)]
+
+
 def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     """Parallel refinement of all starting poses; returns [t (3,1), R (3,3), loss ()] of the candidate whose LAST
     forward had the smallest loss (omniloc.py:271).  Keeps the reference's clamp lag (omniloc.py:260-269): the

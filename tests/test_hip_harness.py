@@ -152,3 +152,20 @@ def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
     # an all-black query image: every block is empty -> all scores 0 (no NaN)
     z = ops.hist_trim_scores(torch.zeros_like(I), cloud, tr, ro, nh, nw).cpu().numpy()
     assert (z == 0).all()
+
+
+def test_omniloc_all_equals_sequential_calls():
+    """omniloc_all = the reference's `for i: omniloc(..., i, ...)` loop in one launch chain, result by result."""
+    from piccolo_amd import omniloc as po
+    g = load_golden("g5_trajectories.npz")
+    import json
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    dev = torch.device("cuda")
+    I, X, C = [torch.from_numpy(g[k]).to(dev) for k in ("img", "xyz", "rgb")]
+    t_all, r_all = torch.from_numpy(g["trans0"].copy()).to(dev), torch.from_numpy(g["rot0"].copy()).to(dev)
+    together = po.omniloc_all(I, X, C, t_all, r_all, cfg)
+    t_seq, r_seq = torch.from_numpy(g["trans0"].copy()).to(dev), torch.from_numpy(g["rot0"].copy()).to(dev)
+    for i in range(4):
+        single = po.omniloc(I, X, C, t_seq, r_seq, i, cfg, {})
+        assert all(torch.equal(a, b) for a, b in zip(single, together[i])), i
+    assert torch.equal(t_all, t_seq) and torch.equal(r_all, r_seq)      # the callers' rows end up identical too
