@@ -74,6 +74,7 @@ int pcl_pano_pack_u8(const float *img_hwc, int H, int W, uint32_t *pano, int *no
  *   visible : nullable uint8 [B][n] in PACKED point order, multiplied into the mask (build-defined depth mask,
  *             off in the reference; see pcl_scatter_min_depth)
  * loss = sum_i mask_i ||c_i - rgb_i||_2 / sum_i mask_i, mask_i = sampled colour not exactly (0,0,0); 0/0 -> NaN.
+ * Limits (32-bit buffer addressing): n <= 2^27 points, packed panorama < 2 GiB; PCL_EINVAL beyond.
  */
 size_t pcl_loss_workspace_bytes(int64_t n, int B);
 int pcl_sampling_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans,

@@ -406,6 +406,8 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
                     int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s)
 {
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8) return PCL_EINVAL;
+    // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
+    if (n > (int64_t)1 << 27 || (int64_t)(H + 2) * (W + 2) * (pano_format == PCL_PANO_U8 ? 4 : 16) >= ((int64_t)1 << 31)) return PCL_EINVAL;
     PclPlan p = pcl_plan(n, B);
     PclLossArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
