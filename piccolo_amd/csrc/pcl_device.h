@@ -47,6 +47,7 @@ struct PclDims {
     float off_x, off_y;      // (W-1)/2 + 1, (H-1)/2 + 1 : pixel coordinate in the zero-bordered texture
     float k_phi, k_theta;    // -W/(2 pi), H/pi     (d ix / d phi, d iy / d theta); times 1/255 for RGBA8 texels
     float c_scale;           // texel level -> colour: 1 (float texels) or 1/255 (RGBA8)
+    float k_ix, k_iy;        // d ix / d phi = -W/(2 pi), d iy / d elevation = -H/pi   (pixel from the angles directly)
 };
 
 __host__ __device__ inline PclDims pcl_make_dims(int H, int W, int pano_format = PCL_PANO_F32)
@@ -58,6 +59,8 @@ __host__ __device__ inline PclDims pcl_make_dims(int H, int W, int pano_format =
     d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846));
     d.k_theta = (float)((double)H / 3.14159265358979323846);
     d.c_scale = 1.0f;
+    d.k_ix = (float)(-(double)W / (2.0 * 3.14159265358979323846));
+    d.k_iy = (float)(-(double)H / 3.14159265358979323846);
     if (pano_format == PCL_PANO_U8) {
         d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846) / 255.0);
         d.k_theta = (float)((double)H / 3.14159265358979323846 / 255.0);

@@ -60,20 +60,38 @@ __device__ __forceinline__ f2 pcl_atan_poly2(f2 t)
     return p * t;
 }
 
-template <bool SIGNED_Y>
+// first-octant angle atan(min/max) of two magnitudes (packed) and the "second is larger" flags
+__device__ __forceinline__ f2 pcl_atan_ratio2(float u0, float v0, float u1, float v1)
+{
+    f2 mn = {fminf(u0, v0), fminf(u1, v1)};
+    f2 rc = {__builtin_amdgcn_rcpf(fmaxf(fmaxf(u0, v0), 1e-37f)), __builtin_amdgcn_rcpf(fmaxf(fmaxf(u1, v1), 1e-37f))};
+    return pcl_atan_poly2(mn * rc);
+}
+
+// phi = atan2(y, x) in (-pi, pi]: octant swap by select, the x < 0 reflection and the sign of y by sign transfers:
+//   x < 0 ? pi - r : r  ==  pi/2 - copysign(pi/2 - r, x)        (r in [0, pi/2])
 __device__ __forceinline__ f2 pcl_atan2_2(f2 y, f2 x)
 {
-    const float pi = 3.14159265358979323846f, half_pi = 1.57079632679489661923f;
+    const float half_pi = 1.57079632679489661923f;
     float ax0 = fabsf(x.x), ax1 = fabsf(x.y), ay0 = fabsf(y.x), ay1 = fabsf(y.y);
-    f2 mn = {fminf(ax0, ay0), fminf(ax1, ay1)};
-    f2 rc = {__builtin_amdgcn_rcpf(fmaxf(fmaxf(ax0, ay0), 1e-37f)), __builtin_amdgcn_rcpf(fmaxf(fmaxf(ax1, ay1), 1e-37f))};
-    f2 r = pcl_atan_poly2(mn * rc);
+    f2 r = pcl_atan_ratio2(ax0, ay0, ax1, ay1);
     f2 alt = F2(half_pi) - r;
     r = (f2){ay0 > ax0 ? alt.x : r.x, ay1 > ax1 ? alt.y : r.y};
-    alt = F2(pi) - r;
-    r = (f2){x.x < 0.f ? alt.x : r.x, x.y < 0.f ? alt.y : r.y};
-    if (SIGNED_Y) r = (f2){copysignf(r.x, y.x), copysignf(r.y, y.y)};
-    return r;
+    f2 w = F2(half_pi) - r;
+    w = (f2){copysignf(w.x, x.x), copysignf(w.y, x.y)};
+    r = F2(half_pi) - w;
+    return (f2){copysignf(r.x, y.x), copysignf(r.y, y.y)};
+}
+
+// elevation e = atan2(z, rho) in [-pi/2, pi/2] for rho >= 0: no x < 0 case at all; theta = pi/2 - e
+__device__ __forceinline__ f2 pcl_elevation2(f2 z, f2 rho)
+{
+    const float half_pi = 1.57079632679489661923f;
+    float az0 = fabsf(z.x), az1 = fabsf(z.y);
+    f2 r = pcl_atan_ratio2(rho.x, az0, rho.y, az1);
+    f2 alt = F2(half_pi) - r;
+    r = (f2){az0 > rho.x ? alt.x : r.x, az1 > rho.y ? alt.y : r.y};
+    return (f2){copysignf(r.x, z.x), copysignf(r.y, z.y)};
 }
 
 // Raw 2x2 footprint of one point as it arrives from memory: RGBA8 -> two 8-byte texel pairs; float4 -> four taps.
@@ -123,7 +141,6 @@ template <int FMT>
 __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __restrict__ R, const float* __restrict__ t,
                                              __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
 {
-    const float inv_pi = 0.31830988618379067154f;
     // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
     f2 qx = x - F2(t[0]), qy = y - F2(t[1]), qz = z - F2(t[2]);
     o.px = pcl_fma2(F2(R[2]), qz, pcl_fma2(F2(R[1]), qy, F2(R[0]) * qx));
@@ -137,15 +154,16 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     f2 rg = o.rho2 + F2(1e-37f);
     o.rinv = (f2){__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
     f2 rho = o.rho2 * o.rinv;
-    f2 phi = pcl_atan2_2<true>(o.py, a);
-    f2 theta = pcl_atan2_2<false>(rho, b);
-    f2 gx = phi * F2(-inv_pi);
-    f2 gy = pcl_fma2(theta, F2(2.0f * inv_pi), F2(-1.0f));
-    // sample_from_img (utils.py:97-98): clip to +-0.99, unnormalise (align_corners=False), +1 for the zero border
-    f2 gxc = {__builtin_amdgcn_fmed3f(gx.x, -0.99f, 0.99f), __builtin_amdgcn_fmed3f(gx.y, -0.99f, 0.99f)};
-    f2 gyc = {__builtin_amdgcn_fmed3f(gy.x, -0.99f, 0.99f), __builtin_amdgcn_fmed3f(gy.y, -0.99f, 0.99f)};
-    f2 ix = pcl_fma2(gxc, F2(dm.half_w), F2(dm.off_x));
-    f2 iy = pcl_fma2(gyc, F2(dm.half_h), F2(dm.off_y));
+    f2 phi = pcl_atan2_2(o.py, a);
+    f2 elev = pcl_elevation2(b, rho);                       // theta = atan2(rho, b) = pi/2 - elev
+    // sample_from_img (utils.py:97-98): g = (-phi/pi, -2 elev/pi) clipped to +-0.99, unnormalised (align_corners=False),
+    // +1 for the zero border.  The clip is applied to the angles (|phi| <= 0.99 pi, |elev| <= 0.495 pi: the same set up to
+    // the last ulp of the threshold) so the pixel coordinate is one fma from the angle.
+    const float lim_phi = 0.99f * 3.14159265358979323846f, lim_el = 0.495f * 3.14159265358979323846f;
+    f2 phic = {__builtin_amdgcn_fmed3f(phi.x, -lim_phi, lim_phi), __builtin_amdgcn_fmed3f(phi.y, -lim_phi, lim_phi)};
+    f2 elc = {__builtin_amdgcn_fmed3f(elev.x, -lim_el, lim_el), __builtin_amdgcn_fmed3f(elev.y, -lim_el, lim_el)};
+    f2 ix = pcl_fma2(phic, F2(dm.k_ix), F2(dm.off_x));
+    f2 iy = pcl_fma2(elc, F2(dm.k_iy), F2(dm.off_y));
     // ix, iy > 0 inside the border, so truncation == floor and fract == ix - floor(ix)
     pcl_issue_taps(tex, (int)ix.x, (int)iy.x, dm.Wp, o.ta);
     pcl_issue_taps(tex, (int)ix.y, (int)iy.y, dm.Wp, o.tb);
@@ -155,8 +173,8 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     // (the constants carry the 1/255 of RGBA8 levels)
     // (a wave-uniform "no lane is clipped" fast path was tried: the extra basic block costs more in scheduling and
     // registers than the four selects it saves — 155 vs 141 us at cfg 2)
-    o.mphi = (f2){gx.x == gxc.x ? dm.k_phi : 0.f, gx.y == gxc.y ? dm.k_phi : 0.f};
-    o.mth = (f2){gy.x == gyc.x ? dm.k_theta : 0.f, gy.y == gyc.y ? dm.k_theta : 0.f};
+    o.mphi = (f2){phi.x == phic.x ? dm.k_phi : 0.f, phi.y == phic.y ? dm.k_phi : 0.f};
+    o.mth = (f2){elev.x == elc.x ? dm.k_theta : 0.f, elev.y == elc.y ? dm.k_theta : 0.f};
 }
 
 // Phase B: bilinear colour, mask, residual, gradient, accumulate.
