@@ -564,3 +564,35 @@ def test_multi_image_launch_equals_per_image_runs(ops, oracle):
     assert torch.equal(gd.result()[:B], single[0]) and not torch.equal(gd.result()[B:], torch.cat(single[1:]))
     with pytest.raises(ValueError):
         gd.set_panos([ops.Pano(T(np.zeros((32, 64, 3), np.float32)))] * (I * B))
+
+
+def test_gd_sequential_first_iterations_match_reference(ops):
+    """omniloc's sequential mode, free-running on the device, vs the reference's recorded trajectory (G5 seq0)."""
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    hist, res = _gd_hist(ops, g, False, g["trans0"][0:1], g["rot0"][0:1], 3, cfg)
+    assert np.abs(hist[:, 0] - g["seq0_fwd_loss"][:3, 0]).max() <= 2e-5
+    assert np.abs(res[0, 0:3] - g["seq0_fwd_trans"][3, 0]).max() <= 1e-4
+    assert np.abs(res[0, 3:6] - g["seq0_fwd_rot"][3, 0]).max() <= 1e-4
+
+
+def test_end_to_end_pose_inside_reference_self_noise_band(ops):
+    """G11: the reference's full 100-iteration omniloc on a 20k-point room, plus three reruns of the reference itself with
+    the points permuted (its own fp32 self-noise).  The device result must land in that band (50 % slack on its width)."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    g = load_golden("g11_end_to_end.npz")
+    N, seed = int(g["N"]), int(g["seed"])
+    xyz, rgb = synth.box_room(N, seed)
+    img = g["img_u8"].astype(np.float32) / 255.0
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05)
+    res = po.omniloc(T(img), T(xyz), T(rgb), T(g["trans0"].copy()), T(g["rot0"].copy()), 0, cfg, {})
+    t_err, r_err = synth.pose_errors(res[0].numpy(), res[1].numpy(), g["t_gt"], synth.rot_from_ypr_np(g["ypr_gt"]))
+    band_t = np.concatenate([g["self_noise"][:, 0], [float(g["t_err"])]])
+    band_r = np.concatenate([g["self_noise"][:, 1], [float(g["r_err"])]])
+    wt, wr = band_t.max() - band_t.min(), band_r.max() - band_r.min()
+    assert band_t.min() - 0.5 * wt - 2e-3 <= t_err <= band_t.max() + 0.5 * wt + 2e-3, (t_err, band_t)
+    assert band_r.min() - 0.5 * wr - 0.05 <= r_err <= band_r.max() + 0.5 * wr + 0.05, (r_err, band_r)
+    # and the recovered pose itself is within the reference's run-to-run spread of the reference's pose
+    spread = max(float(g["self_noise"][:, 2].max()), 1e-3)
+    assert np.abs(res[0].numpy() - g["ret_t"]).max() <= 5 * spread, (np.abs(res[0].numpy() - g["ret_t"]).max(), spread)
