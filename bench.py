@@ -118,8 +118,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (PCL_DIST_BACKEND=gloo lets several ranks share one GPU: used by the test-suite to run the N > 1 code path end to
+    #  end on a single-GPU box; the driver's multi-GPU runs use the default, RCCL, one GPU per rank)
+    backend = os.environ.get("PCL_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("PCL_BENCH_FORCE_DIST") == "1":   # (the env knob exercises the RCCL path at world size 1)
         import torch.distributed as dist
@@ -128,7 +132,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)     # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL
+        else:
+            dist.init_process_group(backend)
     _lib.load()
 
     N, H, W, B, batch_mode = WORKLOADS[args.workload]
@@ -222,8 +229,9 @@ def main():
         refine(gi, timer)
     join_streams()
     if dist is not None:                                       # the path's only collective: gather the results
-        gathered = torch.empty(world * n_img, 16, device=dev)
-        dist.all_gather_into_tensor(gathered, results)
+        src = results if backend == "nccl" else results.cpu()
+        gathered = torch.empty(world * n_img, 16, device=src.device)
+        dist.all_gather_into_tensor(gathered, src)
     else:
         gathered = results
     torch.cuda.synchronize()
@@ -231,7 +239,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -169,3 +169,26 @@ def test_omniloc_all_equals_sequential_calls():
         single = po.omniloc(I, X, C, t_seq, r_seq, i, cfg, {})
         assert all(torch.equal(a, b) for a, b in zip(single, together[i])), i
     assert torch.equal(t_all, t_seq) and torch.equal(r_all, r_seq)      # the callers' rows end up identical too
+
+
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here
+    with two ranks sharing the one GPU over gloo: exercises the sharding of query images, the barrier-bracketed timing,
+    the max-over-ranks reduction and the result gather on real kernels."""
+    import json as js
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, PCL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]             # rank 0 prints exactly one JSON line
+    d = js.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "candidate-poses/s"
+    assert d["value"] > 0 and abs(d["value"] - 1 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert d["median_t_err_m"] < 0.1 and "roofline" in d and d["vs_baseline"] is None
