@@ -165,7 +165,7 @@ def main():
     results = torch.zeros(n_img, 16, device=dev)
     # HIP-event pairs around every TIMER_STRIDE-th loss launch of the timed region (each pair costs a few us of GPU
     # timeline; bracketing all 100 launches of a refinement slows cfg 1 by 2x and cfg 2 by ~2 %)
-    timer = ops.KernelTimer(NUM_ITER * K, stride=args.timer_stride)
+    timer = ops.KernelTimer((NUM_ITER // max(1, args.timer_stride) + 1) * K, stride=args.timer_stride)
     # Independent images go to separate HIP streams: one image's optimiser epilogue, kernel boundaries and the tail of
     # its loss kernel overlap with the other image's loss kernel (each GD loop is a strict launch-after-launch chain).
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
