@@ -19,7 +19,7 @@ import torch
 from . import ops
 from .omniloc import packed_cloud, packed_pano
 
-__all__ = ["cloud2idx", "sample_from_img", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
+__all__ = ["cloud2idx", "sample_from_img", "warp_from_img", "reshape_img_tensor", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
            "trim_input_hist_secondary", "make_input", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
            "compute_sampling_grid", "create_coordinate", "write_summaries", "get_bound", "defaultdict", "torch", "np"]
 
@@ -44,6 +44,20 @@ def sample_from_img(img, coord_arr, padding="zeros", mode="bilinear", batched=Fa
         # the reference's batched path squeezes the batch away for B == 1 (utils.py:88) and then fails
         raise RuntimeError("sample_from_img(batched=True) needs B > 1, like the reference")
     return _like(ops.sample_from_img(packed_pano(img), coord_arr), coord_arr)
+
+
+def warp_from_img(img, coord_arr, padding="zeros", mode="bilinear"):
+    """(H,W,3) image sampled at an (H',W',2) grid of coordinates -> (H',W',3) (utils.py:106-131; unused by the reference's
+    own flows, kept for the `from utils import *` surface)."""
+    if padding != "zeros" or mode != "bilinear" or img.shape[-1] != 3:
+        raise NotImplementedError("warp_from_img: bilinear / zeros / 3 channels only")
+    shp = coord_arr.shape
+    return sample_from_img(img, coord_arr.reshape(-1, 2)).reshape(shp[0], shp[1], 3)
+
+
+def reshape_img_tensor(img, size):
+    raise NotImplementedError("reshape_img_tensor resizes through cv2 on the host (utils.py:632-638): not part of the "
+                              "GPU path; resize the image before handing it over")
 
 
 def rot_from_ypr(ypr_array):

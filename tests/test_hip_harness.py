@@ -192,3 +192,14 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "candidate-poses/s"
     assert d["value"] > 0 and abs(d["value"] - 1 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert d["median_t_err_m"] < 0.1 and "roofline" in d and d["vs_baseline"] is None
+
+
+def test_warp_from_img_matches_golden_samples():
+    """warp_from_img == sample_from_img on a grid of coordinates (G2's reference samples, reshaped)."""
+    from piccolo_amd import utils
+    g = load_golden("g2_sample_from_img.npz")
+    coord = torch.from_numpy(g["coord"][:1200].reshape(30, 40, 2)).cuda()
+    out = utils.warp_from_img(torch.from_numpy(g["img"]).cuda(), coord).cpu().numpy()
+    assert out.shape == (30, 40, 3) and np.abs(out.reshape(-1, 3) - g["rgb"][:1200]).max() <= 2e-6
+    with pytest.raises(NotImplementedError):
+        utils.reshape_img_tensor(torch.zeros(4, 4, 3), (2, 2))
