@@ -143,7 +143,8 @@ def test_pano_format_selection_and_float_image(ops, oracle):
 
 
 @pytest.mark.parametrize("n,H,W,B", [(1, 64, 128, 1), (255, 64, 128, 3), (257, 16, 32, 2), (10_000, 128, 256, 5),
-                                     (100_000, 256, 512, 1), (200_003, 256, 512, 8)])
+                                     (100_000, 256, 512, 1), (200_003, 256, 512, 8), (50_021, 101, 203, 5),
+                                     (513, 7, 9, 2), (1025, 300, 100, 4)])
 def test_sampling_loss_vs_oracle(ops, oracle, n, H, W, B):
     """Ragged sizes (n not a multiple of the block, B odd / even / multiple of 4, H < 100 so border taps occur)."""
     from piccolo_amd import synth
@@ -156,10 +157,12 @@ def test_sampling_loss_vs_oracle(ops, oracle, n, H, W, B):
     ref32 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float32)
     # count: points whose sampled colour is exactly black; a pixel-boundary flip between fp32 and fp64 evaluation can
     # move a handful of points in or out
-    assert np.abs(out[:, 1] - ref["count"]).max() <= max(2, 2e-5 * n)
-    assert rel(out[:, 0], ref["loss"]) <= 1e-5
+    dcount = np.abs(out[:, 1] - ref["count"]).max()
+    assert dcount <= max(2, 2e-5 * n)
+    # a point that flips between masked and kept moves the mean loss (and the gradient) by ~1/n of its scale
+    assert rel(out[:, 0], ref["loss"]) <= 1e-5 + 2.0 * dcount / n
     gap = max(rel(ref32["grad_t"], ref["grad_t"]), rel(ref32["grad_ypr"], ref["grad_ypr"]))
-    tol = max(3 * gap, 2e-4) if n >= 255 else 1e-2
+    tol = (max(3 * gap, 2e-4) if n >= 255 else 1e-2) + 20.0 * dcount / n
     assert rel(out[:, 2:5], ref["grad_t"]) <= tol
     assert rel(out[:, 5:8], ref["grad_ypr"]) <= tol
 
