@@ -70,7 +70,7 @@ class PiccoloHipError(RuntimeError):
 
 
 def so_path():
-    return _build.SO
+    return os.environ.get("PCL_SO", _build.SO)       # PCL_SO: A/B a differently built library (experiments)
 
 
 def load():

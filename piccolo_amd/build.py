@@ -35,6 +35,7 @@ def stale():
 
 
 def build(force=False, verbose=False, extra_flags=()):
+    extra_flags = list(extra_flags) + os.environ.get("PCL_HIPCC_FLAGS", "").split()     # experiments only
     if not force and not stale():
         return SO
     os.makedirs(OUT_DIR, exist_ok=True)
