@@ -1,10 +1,16 @@
-// pcl_gd_device.h — device-side pieces of the GD epilogue, shared by pcl_gd.hip (stand-alone epilogue kernel) and
-// pcl_loss.hip (fused variant: the last-arriving block of a pose group finishes the group's poses).
+// pcl_gd_device.h — device-side pieces of the GD epilogue (second-stage reduction, chain rule, optimiser update).
+//
+// Measured and rejected (round 1): running pcl_gd_finish_pose inside pcl_loss_kernel, in the block that draws the last
+// ticket of its pose group (write-through partial stores -> drain -> relaxed agent-scope ticket; last arriver: agent
+// acquire -> reduce -> update), so that an iteration is ONE launch.  Bit-identical to the two-kernel path, but slower:
+// cfg2 (B = 32) 119.2 vs 116.5 us per iteration, cfg1 10.9 vs 9.4 us; with a release fence per block in place of the
+// sc1 stores 154.9 us (4096 L2 write-backs per launch).  The ticket round trip + acquire on the critical path of the
+// last group cost more than the launch boundary they replace.
 #pragma once
 #include "pcl_device.h"
 
 // Deterministic second-stage sum of the per-chunk partials of pose `b` (fixed lane->chunk assignment, double).
-__device__ inline void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, int lane, double out[PCL_NACC])
+__device__ __forceinline__ void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, int lane, double out[PCL_NACC])
 {
     double s[PCL_NACC];
 #pragma unroll
@@ -22,12 +28,13 @@ __device__ inline void pcl_reduce_partials(const float* __restrict__ partials, i
 // loss and gradient w.r.t. (t, yaw, pitch, roll) from the 8 sums, at pose p = (t, yaw, pitch, roll).
 //   dL/dt = -R^T sum g / M ;  dL/dyaw = e_z . T/M ; dL/dpitch = (RZ e_y) . T/M ; dL/droll = (RZ RY e_x) . T/M
 // with T = sum p x g (see pcl_loss.hip).  M = 0 gives NaN like the reference's 0/0.
-__device__ inline void pcl_chain_rule(const double s[PCL_NACC], const float R[9], double sy, double cy, double sp, double cp,
+__device__ __forceinline__ void pcl_chain_rule(const double s[PCL_NACC], const float R[9], double sy, double cy, double sp, double cp,
                                       float& loss, float grad[6])
 {
     double M = s[1];
     loss = (float)s[0] / (float)M;
     double inv = 1.0 / M;
+#pragma unroll
     for (int k = 0; k < 3; k++) grad[k] = (float)(-((double)R[k] * s[2] + (double)R[3 + k] * s[3] + (double)R[6 + k] * s[4]) * inv);
     grad[3] = (float)(s[7] * inv);
     grad[4] = (float)((-sy * s[5] + cy * s[6]) * inv);
@@ -35,9 +42,8 @@ __device__ inline void pcl_chain_rule(const double s[PCL_NACC], const float R[9]
 }
 
 // One wave (`lane` = 0..63) finishes pose b: deterministic reduction, chain rule, Adam, plateau scheduler, clamp, next
-// pose record.  Called by pcl_gd_epilogue_kernel (one wave per block) and, in the fused variant, by the last-arriving
-// block of a pose group inside pcl_loss_kernel.
-__device__ inline void pcl_gd_finish_pose(const float* __restrict__ partials, int nchunks, int B, int b, int lane, PclGdPose* st,
+// pose record.
+__device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ partials, int nchunks, int B, int b, int lane, PclGdPose* st,
                                           PclPoseRec* recs, const float* __restrict__ box, double factor, int patience, int mode,
                                           float* loss_out)
 {
@@ -84,12 +90,16 @@ __device__ inline void pcl_gd_finish_pose(const float* __restrict__ partials, in
 
     // clamp t to the quantile box; batch mode forwards the pre-clamp copy (omniloc.py:260-269), sequential mode
     // clamps the very tensor the next forward reads (omniloc.py:56-58)
-    if (mode == PCL_GD_BATCH)
+    if (mode == PCL_GD_BATCH) {
+#pragma unroll
         for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    }
+#pragma unroll
     for (int k = 0; k < 3; k++) g.leaf[k] = fminf(fmaxf(g.leaf[k], box[2 * k]), box[2 * k + 1]);
-    if (mode != PCL_GD_BATCH)
+    if (mode != PCL_GD_BATCH) {
+#pragma unroll
         for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    }
     pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
     st[b] = g;
 }
-
