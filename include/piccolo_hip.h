@@ -181,6 +181,34 @@ int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, in
 size_t pcl_depth_workspace_bytes(int B, int H, int W);
 int pcl_depth_mask(const float *cloud, int64_t n, const float *trans, const float *rot, int B, int H, int W, float tau,
                    uint8_t *visible, void *workspace, size_t workspace_bytes, void *stream);
+/* ---- colour preprocessing of the query panorama (color_utils.py; called at localize.py:173-179, :395-409) ----
+ *
+ * pcl_color_template_build: the point colours rgb [n][3] sorted per channel, tmpl [3][n] — once per cloud.
+ * pcl_color_match (color_utils.py:146-234): histogram matching of the non-black pixels of img [H][W][3] (levels k/255,
+ *   as decoded from an image file) to the point colours, per channel, with sin(latitude) pixel weights, the reference's
+ *   wrapped interpolation (period 360) and its rank-indexed lookup.  out [H][W][3]; black pixels are copied.
+ *   *not_exact (device int32, nullable) = 1 when some non-black pixel channel is not exactly k/255: the output is then
+ *   not the reference's (its lookup is by distinct float value) and the Python layer raises.
+ * pcl_color_mod (color_utils.py:7-65): joint luma equalisation.  Panorama (non-black pixels) and point colours go to
+ *   8-bit YCrCb (OpenCV's fixed-point cvtColor, restated), the two Y histograms with num_bins levels are added, Y becomes
+ *   the joint cumulative distribution at its level, back to RGB.  out_img [H][W][3], out_rgb [n][3].
+ * workspace for both: pcl_color_workspace_bytes(). */
+size_t pcl_color_template_bytes(int64_t n);
+size_t pcl_color_template_workspace_bytes(int64_t n);
+int pcl_color_template_build(const float *rgb, int64_t n, float *tmpl, void *workspace, size_t workspace_bytes, void *stream);
+size_t pcl_color_workspace_bytes(void);
+int pcl_color_match(const float *img_hwc, int H, int W, const float *tmpl, int64_t n, float *out, int32_t *not_exact,
+                    void *workspace, size_t workspace_bytes, void *stream);
+int pcl_color_mod(const float *img_hwc, int H, int W, const float *rgb, int64_t n, int num_bins, float *out_img,
+                  float *out_rgb, void *workspace, size_t workspace_bytes, void *stream);
+/* color_utils.py:68-118 histogram (unbatched form): colours img [npix][3] (scaled by 255 first if max(img) <= 1), pixels
+ * with mask[p] != 0, c0 x c1 x c2 bins of size ceil(255 / c); hist [c0*c1*c2] float, index r + c0 g + c0 c1 b;
+ * normalize: hist / (sum + eps) (eps 0 = unbatched form, 1e-6 = the batched form's).  color_utils.py:122-144
+ * histogram_intersection: out[i] = sum_k min(a[i][k], b[i][k]). */
+size_t pcl_histogram_workspace_bytes(int c0, int c1, int c2);
+int pcl_histogram(const float *img, const uint8_t *mask, int64_t npix, int c0, int c1, int c2, int normalize, float eps,
+                  float *hist, void *workspace, size_t workspace_bytes, void *stream);
+int pcl_histogram_intersection(const float *a, const float *b, int batch, int nbins, float *out, void *stream);
 /* p = R (x - t) for one pose: xyz [n][3] -> out [n][3] (feeds make_pano / scatter-min; localize.py:266-267). */
 int pcl_transform_cloud(const float *xyz, int64_t n, const float *trans, const float *rot, float *out, void *stream);
 

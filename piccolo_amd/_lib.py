@@ -40,6 +40,15 @@ SIGNATURES = {
     "pcl_gd_workspace_bytes": (_sz, [_i64, _int, _int, _int, _c.POINTER(GdHyper)]),
     "pcl_hist_trim_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
     "pcl_hist_trim_scores": (_int, [_vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_color_template_bytes": (_sz, [_i64]),
+    "pcl_color_template_workspace_bytes": (_sz, [_i64]),
+    "pcl_color_template_build": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "pcl_color_workspace_bytes": (_sz, []),
+    "pcl_color_match": (_int, [_vp, _int, _int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_color_mod": (_int, [_vp, _int, _int, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_histogram_workspace_bytes": (_sz, [_int, _int, _int]),
+    "pcl_histogram": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _c.c_float, _vp, _vp, _sz, _vp]),
+    "pcl_histogram_intersection": (_int, [_vp, _vp, _int, _int, _vp, _vp]),
     "pcl_depth_workspace_bytes": (_sz, [_int, _int, _int]),
     "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _sz, _vp]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),

@@ -1,6 +1,6 @@
 """Thin counterpart of the reference's dataset harness (localize.py) for the part that is on the hot path:
 the per-image body — starting poses -> refinement -> pose error (localize.py:208-258) — plus a synthetic-scene
-driver that needs no dataset.  Dataset IO, colour pre-processing, TensorBoard and result images stay with the
+driver that needs no dataset.  Dataset IO, TensorBoard and result images stay with the
 reference's own localize.py, which runs unchanged on top of piccolo_amd's omniloc/utils.
 """
 import csv
@@ -12,7 +12,23 @@ import torch
 
 from . import dist as pdist
 from . import ops, synth
+from .color_utils import color_match, color_mod
 from .omniloc import omniloc_all, omniloc_batch
+
+
+def preprocess_colors(img, rgb, cfg):
+    """The colour modulation step of the per-image body (localize.py:173-179 for Stanford2D3DS, :395-409 for
+    OmniScenes): cfg.match_color -> color_match(img, rgb); cfg.sharpen_color -> color_mod(img, rgb, cfg.num_bins).
+    As in the reference, both start from the ORIGINAL image (when both are set, color_mod's result is the one kept) and
+    the result is re-quantised to uint8 levels (`(255 * new_img).astype(np.uint8)`, :404, :410).  -> (img, rgb)."""
+    new_img = img
+    if getattr(cfg, "match_color", False):
+        new_img = color_match(img, rgb)
+    if getattr(cfg, "sharpen_color", False):
+        new_img, rgb = color_mod(img, rgb, int(getattr(cfg, "num_bins", 256)))
+    if new_img is not img:
+        new_img = synth.quantise_like_image_file(new_img * 255.0)
+    return new_img, rgb
 
 
 def refine_image(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=None):
@@ -50,11 +66,12 @@ def localize_synthetic(cfg, writer=None, log_dir=None):
         t_gt, ypr_gt = synth.gt_pose(k)
         cam = ops.transform_cloud(xyz, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
         img = synth.quantise_like_image_file(ops.make_pano(cam, rgb, (H, W)))
+        img, rgb_k = preprocess_colors(img, rgb, cfg)
         tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=k, sigma_t=float(getattr(cfg, "start_sigma_t", 0.3)),
                                    sigma_r=float(getattr(cfg, "start_sigma_r", 0.15)))
         torch.cuda.synchronize()
         t0 = time.time()
-        t, R, loss = refine_image(img, xyz, rgb, torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev), cfg)
+        t, R, loss = refine_image(img, xyz, rgb_k, torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev), cfg)
         dt = time.time() - t0
         t_err, r_err = pose_errors(t, R, t_gt, synth.rot_from_ypr_np(ypr_gt))
         return torch.cat([t.reshape(3), R.reshape(9), loss.reshape(1), torch.tensor([t_err, r_err, dt])])

@@ -154,6 +154,77 @@ def depth_mask(cloud, trans, rot, resolution, tau=0.02):
     return vis
 
 
+class ColorTemplate:
+    """The point colours sorted per channel (3, n): what color_match needs from the cloud, built once per cloud."""
+
+    def __init__(self, rgb):
+        lib = _lib.load()
+        rgb = _dev(rgb).reshape(-1, 3)
+        self.n = int(rgb.shape[0])
+        self.data = torch.empty(3, self.n, dtype=F32, device=rgb.device)
+        nws = lib.pcl_color_template_workspace_bytes(self.n)
+        ws = _bytes(nws)
+        _lib.check(lib.pcl_color_template_build(_ptr(rgb), self.n, _ptr(self.data), _ptr(ws), nws, _stream()),
+                   "pcl_color_template_build")
+
+
+def color_match(img, template):
+    """color_utils.color_match (color_utils.py:146-234) on the GPU: img (H,W,3) with levels k/255 -> matched (H,W,3).
+    `template` is a ColorTemplate of the point colours."""
+    lib = _lib.load()
+    img = _dev(img)
+    H, W = int(img.shape[0]), int(img.shape[1])
+    out = torch.empty_like(img)
+    flag = torch.zeros(1, dtype=torch.int32, device=img.device)
+    nws = lib.pcl_color_workspace_bytes()
+    ws = _bytes(nws)
+    _lib.check(lib.pcl_color_match(_ptr(img), H, W, _ptr(template.data), template.n, _ptr(out), _ptr(flag), _ptr(ws), nws,
+                                   _stream()), "pcl_color_match")
+    if int(flag.item()):
+        raise ValueError("color_match: the panorama must hold levels k/255 (an image file's uint8 / 255); "
+                         "found a non-black pixel channel in between")
+    return out
+
+
+def color_mod(img, rgb, num_bins=256):
+    """color_utils.color_mod (color_utils.py:7-65) on the GPU: -> (img (H,W,3), rgb (n,3)) after joint luma equalisation."""
+    lib = _lib.load()
+    img, rgb = _dev(img), _dev(rgb).reshape(-1, 3)
+    H, W = int(img.shape[0]), int(img.shape[1])
+    out_img, out_rgb = torch.empty_like(img), torch.empty_like(rgb)
+    nws = lib.pcl_color_workspace_bytes()
+    ws = _bytes(nws)
+    _lib.check(lib.pcl_color_mod(_ptr(img), H, W, _ptr(rgb), int(rgb.shape[0]), int(num_bins), _ptr(out_img), _ptr(out_rgb),
+                                 _ptr(ws), nws, _stream()), "pcl_color_mod")
+    return out_img, out_rgb
+
+
+def histogram(img, mask, channels, normalize=True, eps=0.0):
+    """color_utils.histogram of one image (color_utils.py:68-103): flat float histogram of c0*c1*c2 bins on the GPU."""
+    lib = _lib.load()
+    img = _dev(img).reshape(-1, 3)
+    mask = _dev(mask != 0, torch.uint8).reshape(-1)
+    c0, c1, c2 = (int(c) for c in channels)
+    nws = lib.pcl_histogram_workspace_bytes(c0, c1, c2)
+    if nws == 0:
+        raise ValueError("histogram: bad bin counts %r" % (channels,))
+    ws = _bytes(nws)
+    hist = torch.empty(c0 * c1 * c2, dtype=F32, device=img.device)
+    _lib.check(lib.pcl_histogram(_ptr(img), _ptr(mask), int(img.shape[0]), c0, c1, c2, int(bool(normalize)), float(eps),
+                                 _ptr(hist), _ptr(ws), nws, _stream()), "pcl_histogram")
+    return hist
+
+
+def histogram_intersection(h1, h2):
+    """(B, nbins) x (B, nbins) -> (B,) sums of element-wise minima (color_utils.py:122-144)."""
+    lib = _lib.load()
+    h1, h2 = _dev(h1), _dev(h2)
+    B, nbins = int(h1.shape[0]), int(h1.shape[1])
+    out = torch.empty(B, dtype=F32, device=h1.device)
+    _lib.check(lib.pcl_histogram_intersection(_ptr(h1), _ptr(h2), B, nbins, _ptr(out), _stream()), "pcl_histogram_intersection")
+    return out
+
+
 def quantile_box(xyz, q):
     """(6,) GPU tensor: x_lo, x_hi, y_lo, y_hi, z_lo, z_hi — utils.py:208-229 on the three columns."""
     lib = _lib.load()

@@ -446,10 +446,60 @@ def g12_trim_input_hist():
     print("G12 scores", np.round(scores, 4))
 
 
+def _colour_case(seed, H, W, n, levels, template):
+    """A quantised panorama (k/255) with a black patch, whose channels use only `levels`, and point colours that are
+    either quantised (k/255, like the datasets' integer RGB columns) or continuous (like the synthetic room)."""
+    rng = np.random.default_rng(seed)
+    img8 = rng.choice(np.asarray(levels, np.uint8), size=(H, W, 3))
+    img8[H // 4:H // 4 + 3, W // 8:W // 2] = 0                  # black (unrendered) pixels stay untouched
+    img8[0, :5] = (0, 0, 7)                                     # non-black through one channel only
+    img = img8.astype(np.float32) / np.float32(255)
+    if template == "quantised":
+        rgb = rng.integers(16, 250, size=(n, 3)).astype(np.float32) / np.float32(255)
+    else:
+        rgb = (rng.random((n, 3)) ** 0.7).astype(np.float32)
+    return img, rgb
+
+
+def g13_color_match():
+    """color_utils.color_match (pure torch: runs here).  Cases: every level present / gaps in the levels (pins the
+    rank-vs-level indexing of _match_cumulative_cdf), quantised and continuous templates."""
+    import color_utils as ref_color
+    out = {}
+    cases = [("full_q", list(range(0, 200)), "quantised"), ("gaps_q", list(range(3, 256, 5)), "quantised"),
+             ("full_c", list(range(0, 256)), "continuous"), ("gaps_c", [0, 1, 2, 40, 41, 90, 200, 255], "continuous")]
+    for i, (name, levels, template) in enumerate(cases):
+        img, rgb = _colour_case(100 + i, 24, 48, 3000, levels, template)
+        res = ref_color.color_match(torch.from_numpy(img.copy()), torch.from_numpy(rgb)).numpy()
+        out[name + "_img"], out[name + "_rgb"], out[name + "_out"] = img, rgb, res
+    save("g13_color_match.npz", **out)
+
+
+def g14_color_mod():
+    """color_utils.color_mod.  It calls cv2.cvtColor, and OpenCV is absent from this image: the two uint8 conversions
+    are injected from oracle/color.py (a restatement of OpenCV's published fixed-point formulas), so this fixture pins
+    everything in color_mod EXCEPT those conversions (masking, uint8 truncation, joint histogram, cumulative table,
+    write-back).  Stated as such in oracle/color.py and DESIGN.md."""
+    import color_utils as ref_color
+    from oracle import color as ocolor
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_RGB2YCR_CB, cv2.COLOR_YCR_CB2RGB = 36, 38
+    cv2.cvtColor = lambda a, code: (ocolor.rgb2ycrcb_u8 if code == 36 else ocolor.ycrcb2rgb_u8)(a)
+    ref_color.cv2 = cv2
+    out = {}
+    for i, (name, bins) in enumerate((("b256", 256), ("b64", 64))):
+        img, rgb = _colour_case(200 + i, 24, 48, 3000, list(range(0, 256)), "quantised")
+        res_img, res_rgb = ref_color.color_mod(torch.from_numpy(img.copy()), torch.from_numpy(rgb.copy()), bins)
+        out[name + "_img"], out[name + "_rgb"] = img, rgb
+        out[name + "_out_img"], out[name + "_out_rgb"] = res_img.numpy(), res_rgb.numpy()
+        out[name + "_bins"] = np.array(bins)
+    save("g14_color_mod.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
