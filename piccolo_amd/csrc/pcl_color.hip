@@ -15,6 +15,11 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #define PCL_CM_LEVELS 256
+// Histogram passes end with one global atomic per occupied bin per block: with thousands of small blocks those atomics
+// (all on the same few hundred addresses) cost more than the streaming pass itself (measured 48 us vs 8 us for a
+// 1024 x 2048 panorama).  One 1024-thread block per CU keeps 16 waves per CU in flight with 8x fewer flushes.
+#define PCL_HBLOCK 1024
+#define PCL_HGRID 256
 #define PCL_CM_FIX 68719476736.0   // 2^36: sin-weights accumulate as 64-bit fixed point (deterministic; <= 2^23+ pixels)
 
 struct PclColorHist {                       // zeroed per call
@@ -76,15 +81,15 @@ extern "C" int pcl_color_template_build(const float* rgb, int64_t n, float* tmpl
 // ------------------------------------------------------------------------------------------- color_match
 
 // Pass 1: per-level sin-weight sums and pixel counts of the non-black pixels, per channel.
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_cm_hist_kernel(const float* __restrict__ img, int H, int W, PclColorHist* hist)
+__global__ void __launch_bounds__(PCL_HBLOCK) pcl_cm_hist_kernel(const float* __restrict__ img, int H, int W, PclColorHist* hist)
 {
     __shared__ unsigned long long wsum[3][PCL_CM_LEVELS];
     __shared__ unsigned int count[3][PCL_CM_LEVELS];
-    for (int k = threadIdx.x; k < 3 * PCL_CM_LEVELS; k += PCL_BLOCK) { (&wsum[0][0])[k] = 0ull; (&count[0][0])[k] = 0u; }
+    for (int k = threadIdx.x; k < 3 * PCL_CM_LEVELS; k += PCL_HBLOCK) { (&wsum[0][0])[k] = 0ull; (&count[0][0])[k] = 0u; }
     __syncthreads();
     const int64_t npix = (int64_t)H * W;
     bool bad = false;
-    for (int64_t p = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; p < npix; p += (int64_t)gridDim.x * PCL_BLOCK) {
+    for (int64_t p = (int64_t)blockIdx.x * PCL_HBLOCK + threadIdx.x; p < npix; p += (int64_t)gridDim.x * PCL_HBLOCK) {
         float v[3] = {img[3 * p], img[3 * p + 1], img[3 * p + 2]};
         int l[3] = {pcl_level(v[0]), pcl_level(v[1]), pcl_level(v[2])};
         if ((int64_t)l[0] + l[1] + l[2] <= 0) continue;                       // color_utils.py:223
@@ -100,7 +105,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_cm_hist_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 3 * PCL_CM_LEVELS; k += PCL_BLOCK) {
+    for (int k = threadIdx.x; k < 3 * PCL_CM_LEVELS; k += PCL_HBLOCK) {
         unsigned int n = (&count[0][0])[k];
         if (n) {
             atomicAdd(&(&hist->count[0][0])[k], n);
@@ -113,18 +118,24 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_cm_hist_kernel(const float* __r
 // fl32(fl32(c) / fl32(n)): the reference's float32 tensor cumsum(counts) / len(template) (color_utils.py:198)
 __device__ __forceinline__ float pcl_cm_quot(int64_t c, float nf) { return __fdiv_rn((float)c, nf); }
 
-__device__ inline int64_t pcl_lower_bound(const float* __restrict__ s, int64_t n, float v)   // #(s < v)
+// #(s < v) and #(s <= v) for a value v that is known to sit at sorted position `pos`: gallop outwards from pos, then
+// bisect — 2-3 loads when the colours are continuous (runs of length 1), O(log run) when they are quantised.
+__device__ inline int64_t pcl_lower_bound_at(const float* __restrict__ s, int64_t pos, float v)
 {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (s[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
+    int64_t hi = pos, lo = pos - 1, step = 1;                    // invariant: s[hi] == v; answer in (lo, hi]
+    while (lo >= 0 && s[lo] == v) { hi = lo; lo -= step; step <<= 1; }
+    if (lo < -1) lo = -1;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (s[mid] < v) lo = mid; else hi = mid; }
+    return hi;
 }
 
-__device__ inline int64_t pcl_upper_bound(const float* __restrict__ s, int64_t n, float v)   // #(s <= v)
+__device__ inline int64_t pcl_upper_bound_at(const float* __restrict__ s, int64_t n, int64_t pos, float v)
 {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (s[mid] <= v) lo = mid + 1; else hi = mid; }
-    return lo;
+    int64_t lo = pos, hi = pos + 1, step = 1;                    // invariant: s[lo] == v; answer in (lo, hi]
+    while (hi < n && s[hi] == v) { lo = hi; hi += step; step <<= 1; }
+    if (hi > n) hi = n;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (s[mid] <= v) lo = mid; else hi = mid; }
+    return hi;
 }
 
 // Pass 2 (one block per channel, one thread per level): quantile of every level, its image under the template CDF with
@@ -138,14 +149,18 @@ __global__ void __launch_bounds__(PCL_CM_LEVELS) pcl_cm_table_kernel(const PclCo
     __shared__ int rank[PCL_CM_LEVELS];
     __shared__ float table[PCL_CM_LEVELS];
     __shared__ int maxbin;
-    if (b == 0) {                                   // 256-entry scans: sequential, exact in double / int
+    cum[b] = (double)hist->wsum[c][b] * (1.0 / PCL_CM_FIX);
+    rank[b] = hist->count[c][b] != 0u;
+    __syncthreads();
+    if (b == 0) {                                   // 256-entry scans in LDS: sequential, exact in double / int
         double acc = 0.0;
         int r = 0, mb = -1;
         for (int k = 0; k < PCL_CM_LEVELS; k++) {
-            acc += (double)hist->wsum[c][k] * (1.0 / PCL_CM_FIX);
+            acc += cum[k];
             cum[k] = acc;
+            int present = rank[k];
             rank[k] = r;
-            if (hist->count[c][k]) { r++; mb = k; }
+            if (present) { r++; mb = k; }
         }
         maxbin = mb;
     }
@@ -158,14 +173,14 @@ __global__ void __launch_bounds__(PCL_CM_LEVELS) pcl_cm_table_kernel(const PclCo
     // position c1 - 1; none -> the wrapped sample past the end
     float xb, fb, xs, fs;
     if (!(pcl_cm_quot(n, nf) > x)) {
-        int64_t c_first = pcl_upper_bound(s, n, s[0]);
+        int64_t c_first = pcl_upper_bound_at(s, n, 0, s[0]);
         xb = __fadd_rn(pcl_cm_quot(c_first, nf), 360.f); fb = s[0];
         xs = pcl_cm_quot(n, nf); fs = s[n - 1];
     } else {
         int64_t lo = 1, hi = n;
         while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (pcl_cm_quot(mid, nf) > x) hi = mid; else lo = mid + 1; }
         fb = s[lo - 1];
-        int64_t c_big = pcl_upper_bound(s, n, fb), c_small = pcl_lower_bound(s, n, fb);
+        int64_t c_big = pcl_upper_bound_at(s, n, lo - 1, fb), c_small = pcl_lower_bound_at(s, lo - 1, fb);
         xb = pcl_cm_quot(c_big, nf);
         if (c_small > 0) { xs = pcl_cm_quot(c_small, nf); fs = s[c_small - 1]; }
         else { xs = __fsub_rn(pcl_cm_quot(n, nf), 360.f); fs = s[n - 1]; }   // wrapped sample before the start
@@ -195,6 +210,12 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_cm_apply_kernel(const float* __
     }
 }
 
+static unsigned color_hgrid(int64_t items)
+{
+    int64_t blocks = (items + PCL_HBLOCK - 1) / PCL_HBLOCK;
+    return (unsigned)(blocks < PCL_HGRID ? (blocks > 0 ? blocks : 1) : PCL_HGRID);
+}
+
 static unsigned color_grid(int64_t items)
 {
     int64_t blocks = (items + PCL_BLOCK - 1) / PCL_BLOCK;
@@ -215,7 +236,7 @@ extern "C" int pcl_color_match(const float* img, int H, int W, const float* tmpl
     const int64_t npix = (int64_t)H * W;
     hipError_t e = hipMemsetAsync(hist, 0, sizeof(PclColorHist), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pcl_cm_hist_kernel, dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, H, W, hist);
+    hipLaunchKernelGGL(pcl_cm_hist_kernel, dim3(color_hgrid(npix)), dim3(PCL_HBLOCK), 0, s, img, H, W, hist);
     hipLaunchKernelGGL(pcl_cm_table_kernel, dim3(3), dim3(PCL_CM_LEVELS), 0, s, hist, tmpl, n, lut);
     hipLaunchKernelGGL(pcl_cm_apply_kernel, dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, npix, lut, out);
     PCL_LAUNCH_CHECK();
@@ -264,13 +285,13 @@ __device__ __forceinline__ int pcl_luma_level(float r, float g, float b, int num
 #define PCL_MOD_MAX_BINS 4096
 
 // Luma histogram of colours [count][3]; `masked`: skip black pixels ((v * 255).long().sum() > 0, color_utils.py:26).
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_mod_hist_kernel(const float* __restrict__ col, int64_t count, int num_bins, int masked,
+__global__ void __launch_bounds__(PCL_HBLOCK) pcl_mod_hist_kernel(const float* __restrict__ col, int64_t count, int num_bins, int masked,
                                                                  unsigned int* __restrict__ hist)
 {
     __shared__ unsigned int h[PCL_MOD_MAX_BINS];
-    for (int k = threadIdx.x; k < num_bins; k += PCL_BLOCK) h[k] = 0u;
+    for (int k = threadIdx.x; k < num_bins; k += PCL_HBLOCK) h[k] = 0u;
     __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; p < count; p += (int64_t)gridDim.x * PCL_BLOCK) {
+    for (int64_t p = (int64_t)blockIdx.x * PCL_HBLOCK + threadIdx.x; p < count; p += (int64_t)gridDim.x * PCL_HBLOCK) {
         float r = col[3 * p], g = col[3 * p + 1], b = col[3 * p + 2];
         if (masked && (int64_t)pcl_level(r) + pcl_level(g) + pcl_level(b) <= 0) continue;
         int cr, cb;
@@ -278,25 +299,37 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_mod_hist_kernel(const float* __
         atomicAdd(&h[min(max(lev, 0), num_bins - 1)], 1u);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < num_bins; k += PCL_BLOCK)
+    for (int k = threadIdx.x; k < num_bins; k += PCL_HBLOCK)
         if (h[k]) atomicAdd(&hist[k], h[k]);
 }
 
 // Joint cumulative table (color_utils.py:40-44): float32 histograms added, divided by their float32 sum, prefix sums
 // accumulated in double and rounded per entry (torch.cumsum on a float32 CPU tensor).
-__global__ void pcl_mod_table_kernel(const unsigned int* __restrict__ hist_img, const unsigned int* __restrict__ hist_rgb, int num_bins,
-                                     float* __restrict__ cdf)
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_mod_table_kernel(const unsigned int* __restrict__ hist_img, const unsigned int* __restrict__ hist_rgb,
+                                                                  int num_bins, float* __restrict__ cdf)
 {
-    if (blockIdx.x | threadIdx.x) return;
-    unsigned long long total = 0;
-    for (int k = 0; k < num_bins; k++) total += (unsigned long long)hist_img[k] + hist_rgb[k];
-    float tf = (float)total;
-    double acc = 0.0;
-    for (int k = 0; k < num_bins; k++) {
-        float v = __fdiv_rn(__fadd_rn((float)hist_img[k], (float)hist_rgb[k]), tf);
-        acc += (double)v;
-        cdf[k] = (float)acc;
+    __shared__ float tot[PCL_MOD_MAX_BINS];
+    __shared__ unsigned long long part[PCL_BLOCK / PCL_WAVE];
+    unsigned long long cnt = 0;
+    for (int k = threadIdx.x; k < num_bins; k += PCL_BLOCK) {
+        unsigned int a = hist_img[k], b = hist_rgb[k];
+        tot[k] = __fadd_rn((float)a, (float)b);
+        cnt += (unsigned long long)a + b;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor((long long)cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tf = (float)(part[0] + part[1] + part[2] + part[3]);
+        double acc = 0.0;
+        for (int k = 0; k < num_bins; k++) {                     // sequential: the prefix sums are order dependent
+            acc += (double)__fdiv_rn(tot[k], tf);
+            tot[k] = (float)acc;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < num_bins; k += PCL_BLOCK) cdf[k] = tot[k];
 }
 
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_mod_apply_kernel(const float* __restrict__ col, int64_t count, int num_bins, int masked,
@@ -335,9 +368,9 @@ extern "C" int pcl_color_mod(const float* img, int H, int W, const float* rgb, i
     const int64_t npix = (int64_t)H * W;
     hipError_t e = hipMemsetAsync(hist_img, 0, 2 * PCL_MOD_MAX_BINS * sizeof(unsigned int), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pcl_mod_hist_kernel, dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, npix, num_bins, 1, hist_img);
-    hipLaunchKernelGGL(pcl_mod_hist_kernel, dim3(color_grid(n)), dim3(PCL_BLOCK), 0, s, rgb, n, num_bins, 0, hist_rgb);
-    hipLaunchKernelGGL(pcl_mod_table_kernel, dim3(1), dim3(1), 0, s, hist_img, hist_rgb, num_bins, cdf);
+    hipLaunchKernelGGL(pcl_mod_hist_kernel, dim3(color_hgrid(npix)), dim3(PCL_HBLOCK), 0, s, img, npix, num_bins, 1, hist_img);
+    hipLaunchKernelGGL(pcl_mod_hist_kernel, dim3(color_hgrid(n)), dim3(PCL_HBLOCK), 0, s, rgb, n, num_bins, 0, hist_rgb);
+    hipLaunchKernelGGL(pcl_mod_table_kernel, dim3(1), dim3(PCL_BLOCK), 0, s, hist_img, hist_rgb, num_bins, cdf);
     hipLaunchKernelGGL(pcl_mod_apply_kernel, dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, npix, num_bins, 1, cdf, out_img);
     hipLaunchKernelGGL(pcl_mod_apply_kernel, dim3(color_grid(n)), dim3(PCL_BLOCK), 0, s, rgb, n, num_bins, 0, cdf, out_rgb);
     PCL_LAUNCH_CHECK();
@@ -368,21 +401,21 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_img_max_kernel(const float* __r
 #define PCL_HIST_LDS_BINS 4096
 
 template <bool LDS>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_histogram_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int64_t npix,
+__global__ void __launch_bounds__(PCL_HBLOCK) pcl_histogram_kernel(const float* __restrict__ img, const uint8_t* __restrict__ mask, int64_t npix,
                                                                   int c0, int c1, int c2, const unsigned int* __restrict__ maxkey,
                                                                   unsigned int* __restrict__ hist)
 {
     __shared__ unsigned int h[LDS ? PCL_HIST_LDS_BINS : 1];
     const int nbins = c0 * c1 * c2;
     if (LDS) {
-        for (int k = threadIdx.x; k < nbins; k += PCL_BLOCK) h[k] = 0u;
+        for (int k = threadIdx.x; k < nbins; k += PCL_HBLOCK) h[k] = 0u;
         __syncthreads();
     }
     // `if tgt_img.max() <= 1: tgt_img = (tgt_img * 255).long()` (color_utils.py:88-89)
     const float scale = (*maxkey <= pcl_float_key(1.0f)) ? 255.f : 1.f;
     // bin_size = ceil(255 / channels) (color_utils.py:86)
     const int s0 = (int)ceilf(255.f / (float)c0), s1 = (int)ceilf(255.f / (float)c1), s2 = (int)ceilf(255.f / (float)c2);
-    for (int64_t p = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; p < npix; p += (int64_t)gridDim.x * PCL_BLOCK) {
+    for (int64_t p = (int64_t)blockIdx.x * PCL_HBLOCK + threadIdx.x; p < npix; p += (int64_t)gridDim.x * PCL_HBLOCK) {
         if (!mask[p]) continue;
         int q0 = (int)(img[3 * p] * scale) / s0, q1 = (int)(img[3 * p + 1] * scale) / s1, q2 = (int)(img[3 * p + 2] * scale) / s2;
         int code = q0 + c0 * q1 + c0 * c1 * q2;
@@ -391,7 +424,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_histogram_kernel(const float* _
     }
     if (LDS) {
         __syncthreads();
-        for (int k = threadIdx.x; k < nbins; k += PCL_BLOCK)
+        for (int k = threadIdx.x; k < nbins; k += PCL_HBLOCK)
             if (h[k]) atomicAdd(&hist[k], h[k]);
     }
 }
@@ -432,9 +465,9 @@ extern "C" int pcl_histogram(const float* img, const uint8_t* mask, int64_t npix
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(pcl_img_max_kernel, dim3(color_grid(npix * 3)), dim3(PCL_BLOCK), 0, s, img, npix * 3, maxkey);
     if (nbins <= PCL_HIST_LDS_BINS)
-        hipLaunchKernelGGL((pcl_histogram_kernel<true>), dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, mask, npix, c0, c1, c2, maxkey, counts);
+        hipLaunchKernelGGL((pcl_histogram_kernel<true>), dim3(color_hgrid(npix)), dim3(PCL_HBLOCK), 0, s, img, mask, npix, c0, c1, c2, maxkey, counts);
     else
-        hipLaunchKernelGGL((pcl_histogram_kernel<false>), dim3(color_grid(npix)), dim3(PCL_BLOCK), 0, s, img, mask, npix, c0, c1, c2, maxkey, counts);
+        hipLaunchKernelGGL((pcl_histogram_kernel<false>), dim3(color_hgrid(npix)), dim3(PCL_HBLOCK), 0, s, img, mask, npix, c0, c1, c2, maxkey, counts);
     hipLaunchKernelGGL(pcl_histogram_finish_kernel, dim3(1), dim3(PCL_BLOCK), 0, s, counts, nbins, normalize, eps, hist);
     PCL_LAUNCH_CHECK();
     return 0;
