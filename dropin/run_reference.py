@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Run the REFERENCE's own main.py with its omniloc / utils / parse_utils / color_utils replaced by piccolo_amd.
+"""Run the REFERENCE's own main.py with its omniloc / utils / parse_utils / color_utils / data_utils replaced by piccolo_amd.
 
     python dropin/run_reference.py /path/to/piccolo --config configs/stanford_parallel.ini --log logs/run1
 
 A script's own directory always comes first on sys.path, so the reference's modules would shadow the drop-ins if its
 main.py were started directly; this launcher puts dropin/ and the repo root in front and then executes main.py from
 inside the reference checkout (its relative ./data paths keep working).  Everything else the reference imports
-(localize.py, data_utils.py, cv2, tensorboard) is its own.
+(localize.py, cv2, tensorboard) is its own.
 """
 import os
 import runpy

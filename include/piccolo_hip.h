@@ -212,6 +212,15 @@ int pcl_histogram_intersection(const float *a, const float *b, int batch, int nb
 /* p = R (x - t) for one pose: xyz [n][3] -> out [n][3] (feeds make_pano / scatter-min; localize.py:266-267). */
 int pcl_transform_cloud(const float *xyz, int64_t n, const float *trans, const float *rot, float *out, void *stream);
 
+/* ---- dataset text clouds (host side, no GPU involved) ----
+ * data_utils.py:16-43 read_stanford / :138-163 read_omniscenes parse "x y z r g b" lines with
+ * pandas.read_table(header=None, delim_whitespace=True).values.  pcl_cloud_txt_rows: number of non-blank lines
+ * (< 0: -errno).  pcl_cloud_txt_read: rows x cols doubles, row-major, parsed by `nthreads` threads (0 = all cores)
+ * from an mmap of the file; returns 0, -errno, PCL_EINVAL (bad arguments / row count mismatch) or -(1000 + line) for
+ * the first malformed line (1-based). */
+int64_t pcl_cloud_txt_rows(const char *path);
+int64_t pcl_cloud_txt_read(const char *path, int64_t rows, int cols, double *out, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

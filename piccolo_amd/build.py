@@ -39,7 +39,7 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not stale():
         return SO
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread",
            "-Wall", "-Wno-unused-function", "-o", SO] + list(extra_flags) + sources()
     if verbose:
         print(" ".join(cmd))

@@ -496,10 +496,86 @@ def g14_color_mod():
     save("g14_color_mod.npz", **out)
 
 
+def g15_data_utils():
+    """data_utils.read_stanford / read_omniscenes on a small text cloud written here (integers, decimals, exponents,
+    tabs, blank lines, CRLF, long mantissas) and obtain_gt_stanford / obtain_gt_omniscenes on pose files written here.
+    The fixture holds the text/JSON inputs and what the reference returned for them."""
+    import tempfile
+    import data_utils as ref_data
+    rng = np.random.default_rng(15)
+    lines = []
+    for i in range(300):
+        x, y, z = rng.normal(0, 5, 3)
+        r, g, b = rng.integers(0, 256, 3)
+        style = i % 6
+        if style == 0:
+            lines.append("%.3f %.3f %.3f %d %d %d" % (x, y, z, r, g, b))
+        elif style == 1:
+            lines.append("%.6f\t%.6f\t%.6f\t%d\t%d\t%d" % (x, y, z, r, g, b))
+        elif style == 2:
+            lines.append("  %.8e %.8e %.8e %d %d %d  " % (x, y, z, r, g, b))
+        elif style == 3:
+            lines.append("%.17g %.17g %.17g %d.0 %d.0 %d.0" % (x, y, z, r, g, b))
+        elif style == 4:
+            lines.append("%d %d %d %d %d %d\r" % (int(x), int(y), int(z), r, g, b))
+        else:
+            lines.append("%+.4f -0.0 .5 %d %d %d" % (x, r, g, b))
+        if i % 50 == 49:
+            lines.append("")
+    text = "\n".join(lines) + "\n"
+    out = {"cloud_txt": np.frombuffer(text.encode(), np.uint8)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cloud.txt")
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        xyz, rgb = ref_data.read_stanford(path)
+        out["xyz"], out["rgb"] = xyz, rgb
+        xyz2, rgb2 = ref_data.read_omniscenes(path)
+        assert np.array_equal(xyz, xyz2) and np.array_equal(rgb, rgb2)
+        special = ("nan inf -inf 1e-400 12345678901234567.5 0.1000000000000000055511151231257827\n"
+                   "9007199254740993 1e22 1e23 4.9e-324 0 -0.0\n"
+                   "0.000000000000000000001234567890123456789 1.7976931348623157e308 2.2250738585072014e-308 5e-1 5E+2 00012.50\n")
+        spath = os.path.join(tmp, "special.txt")
+        with open(spath, "w", newline="") as f:
+            f.write(special)
+        sx, sr = ref_data.read_stanford(spath)
+        assert sx.dtype == np.float64 and sr.dtype == np.float64
+        out["special_txt"] = np.frombuffer(special.encode(), np.uint8)
+        out["special"] = np.hstack([sx, sr * 255.])            # (the reference divides the last three columns by 255)
+        out["special_rgb"] = sr
+        np.random.seed(7)
+        xs, rs = ref_data.read_stanford(path, sample_rate=4)
+        out["xyz_s4"], out["rgb_s4"] = xs, rs
+        # ground-truth poses
+        os.makedirs(os.path.join(tmp, "data/stanford/pose/area_3"))
+        os.makedirs(os.path.join(tmp, "data/stanford/pose/area_30"))
+        pose = {"camera_location": [1.25, -3.5, 1.6], "final_camera_rotation": [1.4835, 0.0321, -2.2143]}
+        name = "camera_abc123_office_7_frame_equirectangular_domain_rgb.png"
+        with open(os.path.join(tmp, "data/stanford/pose/area_3/camera_abc123_office_7_frame_equirectangular_domain_pose.json"), "w") as f:
+            json.dump(pose, f)
+        align = np.array([[0.8, -0.6, 0.0, 2.0], [0.6, 0.8, 0.0, -1.0], [0.0, 0.0, 1.0, 0.25]])
+        np.savetxt(os.path.join(tmp, "data/stanford/pose/area_30/office_7.txt"), align)
+        os.makedirs(os.path.join(tmp, "omni/pano"))
+        os.makedirs(os.path.join(tmp, "omni/pose"))
+        omni = np.hstack([np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]), np.array([[0.5], [1.5], [-0.25]])])
+        np.savetxt(os.path.join(tmp, "omni/pose/room_1.txt"), omni)
+        os.chdir(tmp)
+        try:
+            t3, r3 = ref_data.obtain_gt_stanford(3, name)
+            t30, r30 = ref_data.obtain_gt_stanford(30, name)
+            to, ro = ref_data.obtain_gt_omniscenes(os.path.join(tmp, "omni/pano/room_1.jpg"))
+        finally:
+            os.chdir(cwd)
+    out.update(pose_loc=np.array(pose["camera_location"]), pose_rot=np.array(pose["final_camera_rotation"]), align=align, omni=omni,
+               gt3_t=t3, gt3_r=r3, gt30_t=t30, gt30_r=r30, omni_t=to, omni_r=ro)
+    save("g15_data_utils.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue
