@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Entry point with the reference's CLI (main.py:12-16): --config, --log, --override.
 
-dataset = Synthetic runs piccolo_amd.localize.localize_synthetic (no dataset files needed).  For the reference's real
-datasets (Stanford2D-3D-S, OmniScenes) run the reference's own main.py on top of this package — dropin/run_reference.py,
-see INTEGRATION.md: its localize.py then calls piccolo_amd's omniloc / utils unchanged.
+dataset = Synthetic runs piccolo_amd.localize.localize_synthetic (no dataset files needed); Stanford2D-3D-S and OmniScenes
+run piccolo_amd.localize.localize_stanford / localize_omniscenes over ./data/... in the reference's directory layout
+(README.md:40-75 of the reference) and write the reference's CSV.  The reference's own main.py can also be run on top of
+this package — dropin/run_reference.py, see INTEGRATION.md.  With torch.distributed.run the query images are sharded
+over the GPUs.
 """
 import argparse
 import os
@@ -33,25 +35,25 @@ def main():
     with open(os.path.join(args.log, "config.ini"), "w") as f:
         out.write(f)
 
-    if cfg.dataset == "Synthetic":
-        import numpy as np
-        import torch.distributed as dist
-        if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            import torch
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-            dist.init_process_group("nccl")
-        from piccolo_amd.localize import localize_synthetic
-        table = localize_synthetic(cfg, None, args.log).cpu().numpy()
-        if not dist.is_initialized() or dist.get_rank() == 0:
-            print("images %d  median t-err %.4f m  median R-err %.3f deg  mean time %.3f s" % (
-                len(table), np.median(table[:, 13]), np.median(table[:, 14]), table[:, 15].mean()))
-        if dist.is_initialized():
-            dist.destroy_process_group()
-    elif cfg.dataset in ("Stanford2D-3D-S", "OmniScenes"):
-        raise SystemExit("dataset %r needs the reference's dataset harness: run it on top of piccolo_amd with "
-                         "`python dropin/run_reference.py /path/to/piccolo --config ... --log ...` (INTEGRATION.md)" % cfg.dataset)
-    else:
+    if cfg.dataset not in ("Synthetic", "Stanford2D-3D-S", "OmniScenes"):
         raise ValueError(cfg.dataset)
+    import numpy as np
+    import torch.distributed as dist
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    from piccolo_amd import localize
+    run = {"Synthetic": localize.localize_synthetic, "Stanford2D-3D-S": localize.localize_stanford,
+           "OmniScenes": localize.localize_omniscenes}[cfg.dataset]
+    table = run(cfg, None, args.log).cpu().numpy()
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        done = table[~np.isnan(table[:, 13])]
+        print("images %d (%d skipped)  median t-err %.4f m  median R-err %.3f deg  mean time %.3f s" % (
+            len(table), len(table) - len(done), np.median(done[:, 13]) if len(done) else float("nan"),
+            np.median(done[:, 14]) if len(done) else float("nan"), done[:, 15].mean() if len(done) else float("nan")))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

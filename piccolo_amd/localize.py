@@ -1,19 +1,25 @@
-"""Thin counterpart of the reference's dataset harness (localize.py) for the part that is on the hot path:
-the per-image body — starting poses -> refinement -> pose error (localize.py:208-258) — plus a synthetic-scene
-driver that needs no dataset.  Dataset IO, TensorBoard and result images stay with the
-reference's own localize.py, which runs unchanged on top of piccolo_amd's omniloc/utils.
+"""Counterpart of the reference's dataset harness (localize.py): the per-image body — colour preprocessing ->
+starting poses -> refinement -> pose error (localize.py:173-258) —, a synthetic-scene driver that needs no dataset, and
+the two dataset loops `localize_stanford` / `localize_omniscenes` over the reference's directory layout and CSV format.
+The reference's own localize.py also runs unchanged on top of piccolo_amd's modules; the loops here
+exist so that `main.py` works without OpenCV / TensorBoard (images through PIL, an optional writer) and shards the query
+images over the ranks of a process group.
 """
 import csv
+import glob
 import os
+import random
 import time
 
 import numpy as np
 import torch
 
+from . import data_utils
 from . import dist as pdist
 from . import ops, synth
 from .color_utils import color_match, color_mod
 from .omniloc import omniloc_all, omniloc_batch
+from .utils import make_input, make_pano, out_of_room, write_summaries
 
 
 def preprocess_colors(img, rgb, cfg):
@@ -86,3 +92,277 @@ def localize_synthetic(cfg, writer=None, log_dir=None):
             for k, row in enumerate(table.cpu().numpy()):
                 w.writerow([k, row[13], row[14], row[12], row[15]])
     return table
+
+
+# ------------------------------------------------------------------------------------------ dataset harness
+def get_init_dict(cfg):
+    """localize.py:18-73: the initialisation settings make_input reads, with the reference's defaults."""
+    g = lambda k, d: getattr(cfg, k, d)  # noqa: E731
+    return {"xy_only": g("xy_only", True), "num_trans": g("num_trans", 50), "yaw_only": g("yaw_only", True),
+            "num_yaw": g("num_yaw", 4), "num_pitch": g("num_pitch", 0), "num_roll": g("num_roll", 0),
+            "max_yaw": g("max_yaw", 2 * np.pi), "min_yaw": g("min_yaw", 0), "max_pitch": g("max_pitch", 2 * np.pi),
+            "min_pitch": g("min_pitch", 0), "max_roll": g("max_roll", 2 * np.pi), "min_roll": g("min_roll", 0),
+            "z_prior": g("z_prior", None), "dataset": cfg.dataset, "sample_rate_for_init": g("sample_rate_for_init", None),
+            "trans_init_mode": g("trans_init_mode", "quantile"), "x_max": g("x_max", None), "x_min": g("x_min", None),
+            "y_max": g("y_max", None), "y_min": g("y_min", None), "z_max": g("z_max", None), "z_min": g("z_min", None),
+            "num_split_h": g("num_split_h", 2), "num_split_w": g("num_split_w", 4)}
+
+
+def read_image(filename):
+    """RGB uint8 (H,W,3) array of an image file (the reference: cv2.imread + BGR2RGB, localize.py:167)."""
+    from PIL import Image
+    with Image.open(filename) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+
+
+def resize_image(img8, width, height):
+    """uint8 (H,W,3) -> (height,width,3), bilinear with OpenCV's INTER_LINEAR geometry (pixel centres at k + 0.5, edge
+    clamp, no antialiasing; cv2.resize at localize.py:168,211,372).  Identity when the size is unchanged, which is the
+    case for all shipped configs on 2048 x 1024 panoramas.  cv2 interpolates in 11-bit fixed point: results may differ
+    from it by one level — parity unpinned (OpenCV is absent from the build image)."""
+    H, W = img8.shape[:2]
+    if (W, H) == (width, height):
+        return img8
+    fy = (np.arange(height, dtype=np.float64) + 0.5) * (H / height) - 0.5
+    fx = (np.arange(width, dtype=np.float64) + 0.5) * (W / width) - 0.5
+    y0, x0 = np.floor(fy).astype(np.int64), np.floor(fx).astype(np.int64)
+    wy, wx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    a = img8.astype(np.float64)
+    top = a[y0c][:, x0c] * (1 - wx) + a[y0c][:, x1c] * wx
+    bot = a[y1c][:, x0c] * (1 - wx) + a[y1c][:, x1c] * wx
+    return np.clip(np.rint(top * (1 - wy) + bot * wy), 0, 255).astype(np.uint8)
+
+
+def _to_img(img8, dev):
+    return (torch.from_numpy(img8).float() / 255.).to(dev)          # host division, like the reference (localize.py:169)
+
+
+def _fmt(a):
+    return str(np.asarray(a).flatten())[1:-1].replace("\n", "")
+
+
+class _NullWriter:
+    def add_text(self, *a, **k):
+        pass
+
+    def add_scalar(self, *a, **k):
+        pass
+
+
+def _save_result_image(path, gt_img8, xyz, rgb, t, R, resolution):
+    """localize.py:264-279: ground-truth panorama stacked over the cloud rendered from the estimated pose."""
+    from PIL import Image
+    new_xyz = torch.matmul(R.to(xyz.device), (xyz - t.reshape(1, 3).to(xyz.device)).t()).t()
+    render = make_pano(new_xyz, rgb, resolution=resolution)
+    gt = resize_image(gt_img8, render.shape[1], render.shape[0])
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(np.concatenate([gt, np.asarray(render, np.uint8)], axis=0)).save(path)
+
+
+def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, row_prefix):
+    """Shared loop of the two dataset harnesses: shard the query images over the ranks, run `per_image(k)` ->
+    (RESULT_WIDTH row, gt_trans, gt_rot, skipped), gather, and let rank 0 write the reference's CSV and accuracy."""
+    dev = ops.device()
+    writer = writer if writer is not None else _NullWriter()
+    gts = {}
+
+    def body(k):
+        row, gt_t, gt_r, skipped = per_image(k)
+        gts[k] = (gt_t, gt_r, skipped)
+        return row
+
+    table = pdist.localize_sharded(len(filenames), body, dev)
+    rank, world = pdist.world()
+    if world > 1:                                   # ground truths of the other ranks' images, for the CSV
+        for k in range(len(filenames)):
+            if k not in gts:
+                gts[k] = per_image(k, gt_only=True)
+    accuracy, well_posed, total = 0.0, 0, 0
+    failed, skipped_list = [], []
+    scalar_summaries = {"current_accuracy": []}
+    if rank == 0:
+        import contextlib
+        if log_dir is not None:
+            os.makedirs(log_dir, exist_ok=True)
+        with (open(os.path.join(log_dir, csv_name), "w", encoding="utf-8", newline="") if log_dir is not None
+              else contextlib.nullcontext(open(os.devnull, "w"))) as f:
+            w = csv.writer(f)
+            w.writerow(header)
+            for k, row in enumerate(table.cpu().numpy()):
+                gt_t, gt_r, skipped = gts[k]
+                if skipped:
+                    skipped_list.append(filenames[k])
+                    writer.add_text("skipped rooms", filenames[k])
+                    w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 1])
+                    continue
+                t_err, r_err = float(row[13]), float(row[14])
+                if t_err < 0.2 and r_err < np.rad2deg(0.2):          # localize.py:250
+                    well_posed += 1
+                else:
+                    failed.append(filenames[k])
+                    writer.add_text("failed rooms", filenames[k])
+                total += 1
+                accuracy = well_posed / total
+                scalar_summaries["current_accuracy"].append(accuracy)
+                w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 0, _fmt(row[0:3]), _fmt(row[3:12]), t_err, r_err,
+                                                       float(row[15])])
+        writer.add_scalar("final accuracy", accuracy)
+        print("Final Accuracy : {}".format(accuracy))
+        print("failed {} rooms : {}\n".format(len(failed), failed))
+        print("skipped {} rooms : {}".format(len(skipped_list), skipped_list))
+    return table
+
+
+def _seed_all():
+    torch.manual_seed(2)                            # localize.py:95-98
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(2)
+    np.random.seed(2)
+    random.seed(2)
+
+
+def _nan_row():
+    return torch.full((pdist.RESULT_WIDTH,), float("nan"))
+
+
+def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries):
+    """localize.py:199-247: make_input on the initialisation image, refinement on the main image, errors."""
+    init_dict = get_init_dict(cfg)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    input_trans, input_rot = make_input(img_init, xyz, rgb, getattr(cfg, "num_input", 6), init_dict,
+                                        getattr(cfg, "criterion", "histogram"), getattr(cfg, "num_intermediate", 20))
+    t, R, loss = refine_image(img_main, xyz, rgb, input_trans, input_rot, cfg, summaries)
+    dt = time.time() - t0
+    t_err, r_err = pose_errors(t, R, gt_trans, gt_rot)
+    return t, R, torch.cat([t.reshape(3), R.reshape(9), loss.reshape(1), torch.tensor([t_err, r_err, dt], dtype=torch.float32)])
+
+
+def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford"):
+    """Stanford2D-3D-S loop (localize.py:76-297) over `root`/pano/area_*/ *.png, pcd_not_aligned/area_*/<room>.txt and
+    pose/area_*/ *.json; writes `stanford_results.csv` with the reference's columns and result images under results/."""
+    _seed_all()
+    dev = ops.device()
+    area_num = getattr(cfg, "area", None)
+    # the reference's sort key (room type, room number) leaves the cameras of one room in glob order; names break the tie here
+    key = lambda x: (x.split("/")[-1].split("_")[2], int(x.split("/")[-1].split("_")[3]))  # noqa: E731
+    if area_num is not None:
+        areas = area_num if isinstance(area_num, list) else [area_num]
+        filenames = []
+        for a in areas:
+            filenames += sorted(sorted(glob.glob(os.path.join(root, "pano/area_{}/*.png".format(a)))), key=key)
+    else:
+        filenames = sorted(sorted(glob.glob(os.path.join(root, "pano/area_*/*.png"))),
+                           key=lambda x: (int(x.split("/")[-2].replace("area_", "")),) + key(x))
+    room_name = getattr(cfg, "room_name", None)
+    if room_name is not None:
+        filenames = [f for f in filenames if room_name in f]
+    sample_rate = getattr(cfg, "sample_rate", 1)
+    quant = getattr(cfg, "out_of_room_quantile", 0.05)
+    dh, dw = getattr(cfg, "init_downsample_h", 1), getattr(cfg, "init_downsample_w", 1)
+    mh, mw = getattr(cfg, "main_downsample_h", 1), getattr(cfg, "main_downsample_w", 1)
+    cache = {}
+    summaries = {}
+
+    def per_image(k, gt_only=False):
+        filename = filenames[k]
+        area = int(filename.split("/")[-2].split("_")[-1])
+        img_name = filename.split("/")[-1]
+        room_type, room_no = img_name.split("_")[2], img_name.split("_")[3]
+        gt_trans, gt_rot = data_utils.obtain_gt_stanford(area, img_name, root=os.path.join(root, "pose"))
+        gt_trans, gt_rot = gt_trans.astype(np.float32), gt_rot.astype(np.float32)
+        pcd_name = os.path.join(root, "pcd_not_aligned/area_{}/{}_{}.txt".format(area, room_type, room_no))
+        if cache.get("name") != pcd_name:
+            xyz_np, rgb_np = data_utils.read_stanford(pcd_name, sample_rate)
+            cache.update(name=pcd_name, xyz=torch.from_numpy(xyz_np).float().to(dev), rgb=torch.from_numpy(rgb_np).float().to(dev))
+        xyz, rgb = cache["xyz"], cache["rgb"]
+        skipped = bool(out_of_room(xyz, torch.from_numpy(gt_trans), quant)) and not getattr(cfg, "eval_full", False)
+        if gt_only:
+            return gt_trans, gt_rot, skipped
+        if skipped:
+            print("corrupted file : {}, gt_trans is out of the room\n".format(filename))
+            return _nan_row(), gt_trans, gt_rot, True
+        orig = read_image(filename)
+        img = _to_img(resize_image(orig, orig.shape[1] // dw, orig.shape[0] // dh), dev)
+        rgb_k = rgb
+        if getattr(cfg, "sharpen_color", False):        # localize.py:175-179: only the INITIALISATION image is equalised
+            img, rgb_k = color_mod(img, rgb, int(getattr(cfg, "num_bins", 256)))
+        img_main = _to_img(resize_image(orig, orig.shape[1] // mw, orig.shape[0] // mh), dev)      # localize.py:211-213
+        t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries)
+        print("\n{}\ntranslation error : {}\nrotation error : {}\n".format(img_name, float(row[13]), float(row[14])))
+        if log_dir is not None:
+            _save_result_image(os.path.join(log_dir, "results", "area_{}".format(area), img_name), orig, xyz, rgb, t, R,
+                               (img_main.shape[0] // 2, img_main.shape[1] // 2))
+        return row, gt_trans, gt_rot, False
+
+    return _run_dataset(cfg, writer, log_dir, filenames, per_image, "stanford_results.csv",
+                        ["area_num", "pano_name", "gt_trans", "gt_rot", "skipped?", "OmniLoc_trans", "OmniLoc_rot", "t_error (m)",
+                         "r_error (degrees)", "time (s)"],
+                        lambda f: [int(f.split("/")[-2].split("_")[-1]), f.split("/")[-1]])
+
+
+def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscenes"):
+    """OmniScenes loop (localize.py:300-530) over `root`/<split>_pano/<video>/<frame>, pcd/<room>.txt and <split>_pose;
+    writes `omniscenes_results.csv`.  Includes the synthetic illumination changes (synth_const / synth_gamma / synth_wb)
+    and the colour preprocessing of the whole image (match_color / sharpen_color)."""
+    _seed_all()
+    dev = ops.device()
+    split = getattr(cfg, "split_name", "extreme")
+    filenames = sorted(glob.glob(os.path.join(root, "{}_pano/*/*".format(split))))
+    room_name, scene = getattr(cfg, "room_name", None), getattr(cfg, "scene_number", None)
+    if isinstance(room_name, str):
+        filenames = [f for f in filenames if room_name in f]
+    elif isinstance(room_name, list):
+        filenames = [f for f in filenames if any(rm in f for rm in room_name)]
+    if scene is not None:
+        filenames = [f for f in filenames if "scene_{}".format(scene) in f]
+    sample_rate = getattr(cfg, "sample_rate", 1)
+    quant = getattr(cfg, "out_of_room_quantile", 0.05)
+    dh = max(getattr(cfg, "init_downsample_h", 1) // 2, 1)         # "match resolution with stanford" (localize.py:349-350)
+    dw = max(getattr(cfg, "init_downsample_w", 1) // 2, 1)
+    mh, mw = getattr(cfg, "main_downsample_h", 1), getattr(cfg, "main_downsample_w", 1)
+    cache = {}
+    summaries = {}
+
+    def per_image(k, gt_only=False):
+        filename = filenames[k]
+        video = filename.split("/")[-2]
+        room_type, room_no = video.split("_")[1], video.split("_")[2]
+        gt_trans, gt_rot = data_utils.obtain_gt_omniscenes(filename)
+        gt_trans, gt_rot = gt_trans.astype(np.float32), gt_rot.astype(np.float32)
+        pcd_name = os.path.join(root, "pcd/{}_{}.txt".format(room_type, room_no))
+        if cache.get("name") != pcd_name:
+            xyz_np, rgb_np = data_utils.read_omniscenes(pcd_name, sample_rate)
+            cache.update(name=pcd_name, xyz=torch.from_numpy(xyz_np).float().to(dev), rgb=torch.from_numpy(rgb_np).float().to(dev))
+        xyz, rgb = cache["xyz"], cache["rgb"]
+        skipped = bool(out_of_room(xyz, torch.from_numpy(gt_trans), quant))
+        if gt_only:
+            return gt_trans, gt_rot, skipped
+        if skipped:
+            print("corrupted file : {}, gt_trans is out of the room\n".format(filename))
+            return _nan_row(), gt_trans, gt_rot, True
+        orig = resize_image(read_image(filename), 2048, 1024)       # localize.py:372
+        if getattr(cfg, "synth_const", None) is not None:           # synthetic illumination changes, localize.py:375-385
+            orig = orig // cfg.synth_const
+        if getattr(cfg, "synth_gamma", None) is not None:
+            orig = (((orig / 255.) ** cfg.synth_gamma) * 255).astype(np.uint8)
+        if getattr(cfg, "synth_wb", None):
+            for c, gain in enumerate((cfg.synth_r, cfg.synth_g, cfg.synth_b)):
+                orig[..., c] = (((orig[..., c] / 255.) * gain) * 255).astype(np.uint8)
+        new_img, rgb_k = preprocess_colors(_to_img(orig, dev), rgb, cfg)
+        orig = (255 * new_img.cpu().numpy()).astype(np.uint8)
+        img = _to_img(resize_image(orig, orig.shape[1] // dw, orig.shape[0] // dh), dev)
+        img_main = _to_img(resize_image(orig, orig.shape[1] // mw, orig.shape[0] // mh), dev)
+        t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries)
+        print("\n{}/{}\ntranslation error : {}\nrotation error : {}\n".format(video, filename.split("/")[-1], float(row[13]), float(row[14])))
+        if log_dir is not None:
+            _save_result_image(os.path.join(log_dir, "results", video, os.path.splitext(filename.split("/")[-1])[0] + ".png"), orig, xyz,
+                               rgb_k, t, R, (img_main.shape[0] // 2, img_main.shape[1] // 2))
+        return row, gt_trans, gt_rot, False
+
+    return _run_dataset(cfg, writer, log_dir, filenames, per_image, "omniscenes_results.csv",
+                        ["pano_name", "gt_trans", "gt_rot", "skipped?", "OmniLoc_trans", "OmniLoc_rot", "t_error (m)", "r_error (degrees)",
+                         "time (s)"],
+                        lambda f: ["{}/{}".format(f.split("/")[-2], f.split("/")[-1])])
