@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Colour preprocessing on one GPU: time per call (HIP events on the current stream) of the sorted-template build,
-color_match and color_mod, algorithmic GB/s, and the CPU oracle beside it.
+color_match and color_mod, and algorithmic GB/s.
    python tools/color_bench.py [n_points H W]      (defaults: cfg2 sizes, 1e6 colours, 1024 x 2048 panorama)
 
 Algorithmic bytes (fp32 HWC / (n,3) tensors, every pass counted once):
@@ -10,7 +10,6 @@ Algorithmic bytes (fp32 HWC / (n,3) tensors, every pass counted once):
 """
 import os
 import sys
-import time
 
 import numpy as np
 import torch
@@ -47,10 +46,3 @@ rows = [("template build (once per cloud)", timed(lambda: ops.ColorTemplate(C)),
         ("color_mod", timed(lambda: ops.color_mod(img, C, 256)), 36 * (H * W + n))]
 for name, ms, nbytes in rows:
     print("%-34s %8.3f ms  %7.1f GB/s algorithmic (%.1f MB)" % (name, ms, nbytes / ms / 1e6, nbytes / 1e6))
-
-if "--cpu" in sys.argv:
-    from oracle import color as ocolor  # the checker, timed as the CPU baseline only
-    img_np, rgb_np = img.cpu().numpy(), rgb
-    t0 = time.perf_counter(); ocolor.color_match(img_np, rgb_np); t1 = time.perf_counter()
-    ocolor.color_mod(img_np, rgb_np, 256); t2 = time.perf_counter()
-    print("CPU oracle (numpy, 1 core): color_match %.0f ms, color_mod %.0f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
