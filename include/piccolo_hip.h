@@ -54,6 +54,8 @@ const char *pcl_error_string(int code);
  */
 #define PCL_PANO_F32 0
 #define PCL_PANO_U8 1
+#define PCL_PANO_F16 2 /* RGBA half4, 8 B/texel, levels 0..255 held as fp16 (same k/255 images as PCL_PANO_U8; packed by
+                        * pcl_pano_pack_f16): the loss kernel reads the taps with mixed-precision fma, no byte converts */
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
@@ -63,6 +65,7 @@ int pcl_morton_keys(const float *xyz, int64_t n, const float *lo_host, const flo
 size_t pcl_pano_bytes(int H, int W, int pano_format);
 int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream);
 int pcl_pano_pack_u8(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
+int pcl_pano_pack_f16(const float *img_hwc, int H, int W, void *pano, int *not_exact, void *stream);
 
 /* ---- sampling loss (+ gradient) ----------------------------------------------------------------------------
  * Replaces SamplingLoss.forward (omniloc.py:171-202), BatchSamplingLoss.forward (omniloc.py:311-356), the forward

@@ -61,7 +61,7 @@ __host__ __device__ inline PclDims pcl_make_dims(int H, int W, int pano_format =
     d.c_scale = 1.0f;
     d.k_ix = (float)(-(double)W / (2.0 * 3.14159265358979323846));
     d.k_iy = (float)(-(double)H / 3.14159265358979323846);
-    if (pano_format == PCL_PANO_U8) {
+    if (pano_format == PCL_PANO_U8 || pano_format == PCL_PANO_F16) {
         d.k_phi = (float)(-(double)W / (2.0 * 3.14159265358979323846) / 255.0);
         d.k_theta = (float)((double)H / 3.14159265358979323846 / 255.0);
         d.c_scale = (float)(1.0 / 255.0);
@@ -173,6 +173,9 @@ __device__ inline __amdgpu_buffer_rsrc_t pcl_tex_rsrc(const void* pano, int H, i
     return __builtin_amdgcn_make_buffer_rsrc((void*)pano, 0, (int)((size_t)(H + 2) * (size_t)(W + 2) * (size_t)texel_bytes),
                                              0x00020000);
 }
+
+// bytes per texel of a packed panorama format
+__host__ __device__ constexpr int pcl_texel_bytes(int fmt) { return fmt == PCL_PANO_U8 ? 4 : fmt == PCL_PANO_F16 ? 8 : 16; }
 
 typedef int pcl_i2 __attribute__((ext_vector_type(2)));
 // two horizontally adjacent RGBA8 texels in one 8-byte load

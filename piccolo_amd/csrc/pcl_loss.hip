@@ -98,12 +98,19 @@ __device__ __forceinline__ f2 pcl_elevation2(f2 z, f2 rho)
 template <int FMT> struct PclTaps;
 template <> struct PclTaps<PCL_PANO_U8> { pcl_i2 top, bot; };
 template <> struct PclTaps<PCL_PANO_F32> { int voff, row; };  // float4 texels are fetched where they are consumed
+template <> struct PclTaps<PCL_PANO_F16> { pcl_i4 top, bot; };  // two half4 texels per row: (RG, B0) (RG, B0)
 
 __device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_U8>& o)
 {
     int voff = (y0 * Wp + x0) * 4;
     o.top = pcl_texel_pair_u8(tex, voff, 0);
     o.bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
+}
+__device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_F16>& o)
+{
+    int voff = (y0 * Wp + x0) * 8;
+    o.top = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0);
+    o.bot = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0);
 }
 __device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_F32>& o)
 {
@@ -124,6 +131,49 @@ __device__ __forceinline__ void pcl_unpack_taps(__amdgpu_buffer_rsrc_t tex, cons
     pcl_f4 t10 = pcl_texel(tex, r.voff, r.row), t11 = pcl_texel(tex, r.voff + 16, r.row);
     t[0] = t00.x; t[1] = t00.y; t[2] = t00.z; t[3] = t01.x; t[4] = t01.y; t[5] = t01.z;
     t[6] = t10.x; t[7] = t10.y; t[8] = t10.z; t[9] = t11.x; t[10] = t11.y; t[11] = t11.z;
+}
+
+// fp16 texels: the tap differences are exact in fp16 (integers up to 510) and computed two channels per instruction
+// (v_pk_add_f16); the lerps read their fp16 operands directly (v_fma_mix_f32: fp32 fma with fp16 sources), so no tap is
+// ever converted.  Every operand is the same real number as in the RGBA8 path and every fma is the same fp32 fma:
+// results are bit-identical to it.
+typedef _Float16 pcl_h2 __attribute__((ext_vector_type(2)));
+// fma(a, lo/hi half of b, lo/hi half of c) in fp32 with fp16 sources b, c.  (Written as asm: from the C expression the
+// vectoriser pairs the two points' fmas into v_pk_fma_f32 and pays a v_cvt_f32_f16 per operand for it.)
+__device__ __forceinline__ float pcl_mix_lo(float a, pcl_h2 b, pcl_h2 c)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float pcl_mix_hi(float a, pcl_h2 b, pcl_h2 c)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct PclBilerp1 { float top[3], bot[3], dh[3]; };
+template <bool GRAD>
+__device__ __forceinline__ void pcl_bilerp_f16(const PclTaps<PCL_PANO_F16>& r, float fx, float fy, PclBilerp1& o)
+{
+    // (whole-vector bit cast + shuffles: extracting the dwords one by one and casting each to half2 makes this compiler
+    // narrow the 16-byte load to ONE dword and alias all four pairs — ROCm 7.2 clang 22, wrong results)
+    typedef _Float16 pcl_h8 __attribute__((ext_vector_type(8)));
+    pcl_h8 tv = __builtin_bit_cast(pcl_h8, r.top), bv = __builtin_bit_cast(pcl_h8, r.bot);
+    pcl_h2 t00a = __builtin_shufflevector(tv, tv, 0, 1), t00b = __builtin_shufflevector(tv, tv, 2, 3);
+    pcl_h2 t01a = __builtin_shufflevector(tv, tv, 4, 5), t01b = __builtin_shufflevector(tv, tv, 6, 7);
+    pcl_h2 t10a = __builtin_shufflevector(bv, bv, 0, 1), t10b = __builtin_shufflevector(bv, bv, 2, 3);
+    pcl_h2 t11a = __builtin_shufflevector(bv, bv, 4, 5), t11b = __builtin_shufflevector(bv, bv, 6, 7);
+    pcl_h2 dta = t01a - t00a, dtb = t01b - t00b, dba = t11a - t10a, dbb = t11b - t10b;
+    o.top[0] = pcl_mix_lo(fx, dta, t00a); o.bot[0] = pcl_mix_lo(fx, dba, t10a);
+    o.top[1] = pcl_mix_hi(fx, dta, t00a); o.bot[1] = pcl_mix_hi(fx, dba, t10a);
+    o.top[2] = pcl_mix_lo(fx, dtb, t00b); o.bot[2] = pcl_mix_lo(fx, dbb, t10b);
+    if (GRAD) {
+        pcl_h2 dda = dba - dta, ddb = dbb - dtb;
+        o.dh[0] = pcl_mix_lo(fy, dda, dta);
+        o.dh[1] = pcl_mix_hi(fy, dda, dta);
+        o.dh[2] = pcl_mix_lo(fy, ddb, dtb);
+    }
 }
 
 // What the PROJECTION phase of one pose (two points, packed in .x/.y) hands to its SAMPLING phase.
@@ -186,19 +236,32 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
                                             __amdgpu_buffer_rsrc_t tex, const PclDims& dm, f2* acc, int& count)
 {
     const f2 px = o.px, py = o.py, pz = o.pz, fx = o.fx, fy = o.fy;
-    float ta[12], tb[12];
-    pcl_unpack_taps(tex, o.ta, ta);
-    pcl_unpack_taps(tex, o.tb, tb);
-    // bilinear: top/bottom rows, then vertical; both partial derivatives fall out of the same differences
-    f2 c[3], dv[3], dtop[3], dbot[3];
+    f2 c[3], dv[3], dtop[3], dbot[3], dhp[3];
+    if constexpr (FMT == PCL_PANO_F16) {
+        PclBilerp1 ba, bb;
+        pcl_bilerp_f16<GRAD>(o.ta, fx.x, fy.x, ba);
+        pcl_bilerp_f16<GRAD>(o.tb, fx.y, fy.y, bb);
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        f2 t00 = {ta[k], tb[k]}, t01 = {ta[3 + k], tb[3 + k]}, t10 = {ta[6 + k], tb[6 + k]}, t11 = {ta[9 + k], tb[9 + k]};
-        dtop[k] = t01 - t00;
-        dbot[k] = t11 - t10;
-        f2 top = pcl_fma2(fx, dtop[k], t00), bot = pcl_fma2(fx, dbot[k], t10);
-        dv[k] = bot - top;                                                        // dc/diy (in texel levels)
-        c[k] = pcl_fma2(fy, dv[k], top);
+        for (int k = 0; k < 3; k++) {
+            f2 top = {ba.top[k], bb.top[k]};
+            dv[k] = (f2){ba.bot[k], bb.bot[k]} - top;
+            c[k] = pcl_fma2(fy, dv[k], top);
+            if (GRAD) dhp[k] = (f2){ba.dh[k], bb.dh[k]};
+        }
+    } else {
+        float ta[12], tb[12];
+        pcl_unpack_taps(tex, o.ta, ta);
+        pcl_unpack_taps(tex, o.tb, tb);
+        // bilinear: top/bottom rows, then vertical; both partial derivatives fall out of the same differences
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            f2 t00 = {ta[k], tb[k]}, t01 = {ta[3 + k], tb[3 + k]}, t10 = {ta[6 + k], tb[6 + k]}, t11 = {ta[9 + k], tb[9 + k]};
+            dtop[k] = t01 - t00;
+            dbot[k] = t11 - t10;
+            f2 top = pcl_fma2(fx, dtop[k], t00), bot = pcl_fma2(fx, dbot[k], t10);
+            dv[k] = bot - top;                                                    // dc/diy (in texel levels)
+            c[k] = pcl_fma2(fy, dv[k], top);
+        }
     }
     // mask: sampled colour not exactly (0,0,0)                               (omniloc.py:198, :347)
     float m0 = fmaxf(fmaxf(fabsf(c[0].x), fabsf(c[1].x)), fabsf(c[2].x));
@@ -209,7 +272,7 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
              __builtin_popcountll(__builtin_amdgcn_fcmpf(m1, 0.f, 2) & vmask1);
     // d = c - rgb; the packed cloud stores -rgb (pcl_cloud_pack), so this is one fma / add without a negation
     f2 d0, d1, d2;
-    if (FMT == PCL_PANO_U8) {
+    if (FMT != PCL_PANO_F32) {
         d0 = pcl_fma2(c[0], F2(dm.c_scale), ncr); d1 = pcl_fma2(c[1], F2(dm.c_scale), ncg); d2 = pcl_fma2(c[2], F2(dm.c_scale), ncb);
     } else {
         d0 = c[0] + ncr; d1 = c[1] + ncg; d2 = c[2] + ncb;
@@ -221,9 +284,13 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
     acc[0] = pcl_fma2(n2, rn, acc[0]);                                            // ||d|| = n2 * rsqrt(n2)
     if (GRAD) {
         // d||d||/dc = d / ||d||: the 1/||d|| is folded into the two angle factors instead of scaling d three times
-        f2 dh0 = pcl_fma2(fy, dbot[0] - dtop[0], dtop[0]);                       // dc/dix
-        f2 dh1 = pcl_fma2(fy, dbot[1] - dtop[1], dtop[1]);
-        f2 dh2 = pcl_fma2(fy, dbot[2] - dtop[2], dtop[2]);
+        f2 dh0, dh1, dh2;                                                         // dc/dix
+        if constexpr (FMT == PCL_PANO_F16) { dh0 = dhp[0]; dh1 = dhp[1]; dh2 = dhp[2]; }
+        else {
+            dh0 = pcl_fma2(fy, dbot[0] - dtop[0], dtop[0]);
+            dh1 = pcl_fma2(fy, dbot[1] - dtop[1], dtop[1]);
+            dh2 = pcl_fma2(fy, dbot[2] - dtop[2], dtop[2]);
+        }
         f2 sx = pcl_fma2(d0, dh0, pcl_fma2(d1, dh1, d2 * dh2));
         f2 sy = pcl_fma2(d0, dv[0], pcl_fma2(d1, dv[1], d2 * dv[2]));
         f2 dphi = sx * (o.mphi * rn), dth = sy * (o.mth * rn);                    // dL/dphi, dL/dtheta
@@ -258,7 +325,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
     const int chunk = v / a.ngroups, group = v - chunk * a.ngroups;
     const int pose0 = group * G;
 
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, FMT == PCL_PANO_U8 ? 4 : 16);
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     // the cloud through a buffer resource too: 32-bit lane offsets + scalar plane offsets, no 64-bit address math
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
     const int plane = (int)a.stride * 4;
@@ -313,7 +380,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
             __amdgpu_buffer_rsrc_t tg = tex;
             if (pr->pano_lo | pr->pano_hi) {
                 const void* pp = (const void*)(((unsigned long long)pr->pano_hi << 32) | (unsigned long long)pr->pano_lo);
-                tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, FMT == PCL_PANO_U8 ? 4 : 16);
+                tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
             pcl_project2<FMT>(x, y, z, pr->R, pr->t, tg, a.dims, pj);
@@ -423,9 +490,9 @@ static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, bool 
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
                     int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s)
 {
-    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
-    if (n > (int64_t)1 << 27 || (int64_t)(H + 2) * (W + 2) * (pano_format == PCL_PANO_U8 ? 4 : 16) >= ((int64_t)1 << 31)) return PCL_EINVAL;
+    if (n > (int64_t)1 << 27 || (int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
     PclPlan p = pcl_plan(n, B);
     PclLossArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
@@ -435,6 +502,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
     if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
+    else if (pano_format == PCL_PANO_F16) pcl_launch_f<PCL_PANO_F16>(a, p.G, nblk, grad, vis, s);
     else pcl_launch_f<PCL_PANO_F32>(a, p.G, nblk, grad, vis, s);
     PCL_LAUNCH_CHECK();
     return 0;

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __res
 {
     int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
     if (i >= n) return;
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, FMT == PCL_PANO_U8 ? 4 : 16);
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, pcl_texel_bytes(FMT));
     float2 g = reinterpret_cast<const float2*>(coord)[i];
     float gx = __builtin_amdgcn_fmed3f(g.x, -0.99f, 0.99f), gy = __builtin_amdgcn_fmed3f(g.y, -0.99f, 0.99f);
     float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
@@ -51,6 +51,16 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __res
         t01 = {__fdiv_rn(pcl_ub0(top.y), 255.f), __fdiv_rn(pcl_ub1(top.y), 255.f), __fdiv_rn(pcl_ub2(top.y), 255.f), 0.f};
         t10 = {__fdiv_rn(pcl_ub0(bot.x), 255.f), __fdiv_rn(pcl_ub1(bot.x), 255.f), __fdiv_rn(pcl_ub2(bot.x), 255.f), 0.f};
         t11 = {__fdiv_rn(pcl_ub0(bot.y), 255.f), __fdiv_rn(pcl_ub1(bot.y), 255.f), __fdiv_rn(pcl_ub2(bot.y), 255.f), 0.f};
+    } else if (FMT == PCL_PANO_F16) {
+        // fp16 levels: two half4 texels per 16-byte load; (whole-vector cast + shuffles, see pcl_bilerp_f16)
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        int voff = (y0 * Wp + x0) * 8;
+        h8 top = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0));
+        h8 bot = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0));
+        t00 = {__fdiv_rn((float)top[0], 255.f), __fdiv_rn((float)top[1], 255.f), __fdiv_rn((float)top[2], 255.f), 0.f};
+        t01 = {__fdiv_rn((float)top[4], 255.f), __fdiv_rn((float)top[5], 255.f), __fdiv_rn((float)top[6], 255.f), 0.f};
+        t10 = {__fdiv_rn((float)bot[0], 255.f), __fdiv_rn((float)bot[1], 255.f), __fdiv_rn((float)bot[2], 255.f), 0.f};
+        t11 = {__fdiv_rn((float)bot[4], 255.f), __fdiv_rn((float)bot[5], 255.f), __fdiv_rn((float)bot[6], 255.f), 0.f};
     } else {
         int voff = (y0 * Wp + x0) * 16, row = Wp * 16;
         t00 = pcl_texel(tex, voff, 0); t01 = pcl_texel(tex, voff + 16, 0);
@@ -66,10 +76,12 @@ extern "C" int pcl_sample_from_img(const void* pano, int pano_format, int H, int
                                    void* stream)
 {
     if (!pano || !coord || !rgb_out || n <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
-    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     dim3 grid((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK));
     if (pano_format == PCL_PANO_U8)
         hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_U8>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
+    else if (pano_format == PCL_PANO_F16)
+        hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_F16>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
     else
         hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_F32>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
     PCL_LAUNCH_CHECK();

@@ -19,8 +19,8 @@ extern "C" int64_t pcl_cloud_stride(int64_t n) { return n <= 0 ? 0 : ((n + 255) 
 extern "C" size_t pcl_cloud_bytes(int64_t n) { return (size_t)pcl_cloud_stride(n) * 6 * sizeof(float); }
 extern "C" size_t pcl_pano_bytes(int H, int W, int pano_format)
 {
-    if (H <= 0 || W <= 0 || (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8)) return 0;
-    return (size_t)(H + 2) * (size_t)(W + 2) * (pano_format == PCL_PANO_U8 ? 4 : 16);
+    if (H <= 0 || W <= 0 || (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16)) return 0;
+    return (size_t)(H + 2) * (size_t)(W + 2) * (size_t)pcl_texel_bytes(pano_format);
 }
 
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_cloud_pack_kernel(const float* __restrict__ xyz, const float* __restrict__ rgb,
@@ -132,6 +132,41 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8_kernel(const float
         if (bad) *not_exact = 1;
     }
     pano[i] = v;
+}
+
+// half4 texels holding the levels 0..255 as fp16 (exact), for the same k/255 images as RGBA8.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_f16_kernel(const float* __restrict__ img, int H, int W,
+                                                                      pcl_i2* __restrict__ pano, int* __restrict__ not_exact)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    int Wp = W + 2, Hp = H + 2;
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= (int64_t)Wp * Hp) return;
+    int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+    float lv[3] = {0.f, 0.f, 0.f};
+    if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+        const float* s = img + ((int64_t)(yp - 1) * W + (xp - 1)) * 3;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float f = s[c], k = rintf(f * 255.f);
+            bad = bad || !(k >= 0.f && k <= 255.f) || __fdiv_rn(k, 255.f) != f;
+            lv[c] = k;
+        }
+        if (bad) *not_exact = 1;
+    }
+    h2 rg = {(_Float16)lv[0], (_Float16)lv[1]}, b0 = {(_Float16)lv[2], (_Float16)0.f};
+    pano[i] = (pcl_i2){__builtin_bit_cast(int, rg), __builtin_bit_cast(int, b0)};
+}
+
+extern "C" int pcl_pano_pack_f16(const float* img_hwc, int H, int W, void* pano, int* not_exact, void* stream)
+{
+    if (!img_hwc || !pano || !not_exact || H <= 0 || W <= 0) return PCL_EINVAL;
+    int64_t total = (int64_t)(H + 2) * (W + 2);
+    hipLaunchKernelGGL(pcl_pano_pack_f16_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, img_hwc, H, W, (pcl_i2*)pano, not_exact);
+    PCL_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int pcl_pano_pack_u8(const float* img_hwc, int H, int W, uint32_t* pano, int* not_exact, void* stream)

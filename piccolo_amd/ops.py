@@ -5,6 +5,7 @@ Inputs may live on the CPU (the reference's harness hands over whatever `device`
 they are uploaded to cuda:0.  Without a GPU or without the library every call raises — there is no fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -69,9 +70,12 @@ class Cloud:
 class Pano:
     """Query panorama (H,W,3) float packed as zero-bordered texels.
 
-    fmt="auto": RGBA8 texels when every value is exactly k/255 in fp32 (what an 8-bit image file divided by 255 gives,
-    i.e. everything the reference's harness produces), float4 texels otherwise.  The exactness test is one kernel and
-    one 4-byte D2H read per image, outside the GD loop."""
+    fmt="auto": fp16-level texels (half4, 8 B) when every value is exactly k/255 in fp32 (what an 8-bit image file
+    divided by 255 gives, i.e. everything the reference's harness produces), float4 texels otherwise.  "u8" packs the
+    same k/255 images as RGBA8 (4 B/texel: half the footprint, ~5 % slower loss kernel), "f32" forces float4.  The
+    exactness test is one kernel and one 4-byte D2H read per image, outside the GD loop."""
+
+    _PACK = {"f16": ("pcl_pano_pack_f16", _lib.PANO_F16), "u8": ("pcl_pano_pack_u8", _lib.PANO_U8)}
 
     def __init__(self, img, fmt="auto"):
         lib = _lib.load()
@@ -80,14 +84,19 @@ class Pano:
             raise ValueError("img must be (H, W, 3)")
         self.H, self.W = int(img.shape[0]), int(img.shape[1])
         self.fmt = None
-        if fmt in ("auto", "u8"):
-            data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_U8))
+        if fmt == "auto":
+            fmt = os.environ.get("PCL_PANO_FMT", "auto")      # experiments: force a texel format
+        if fmt not in ("auto", "f16", "u8", "f32"):
+            raise ValueError("unknown texel format %r" % (fmt,))
+        if fmt != "f32":
+            fn, code = self._PACK["f16" if fmt == "auto" else fmt]
+            data = _bytes(lib.pcl_pano_bytes(self.H, self.W, code))
             flag = torch.zeros(1, dtype=torch.int32, device=img.device)
-            _lib.check(lib.pcl_pano_pack_u8(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), "pcl_pano_pack_u8")
+            _lib.check(getattr(lib, fn)(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), fn)
             if int(flag.item()) == 0:
-                self.fmt, self.data = _lib.PANO_U8, data
-            elif fmt == "u8":
-                raise ValueError("image is not exactly k/255: cannot use RGBA8 texels")
+                self.fmt, self.data = code, data
+            elif fmt != "auto":
+                raise ValueError("image is not exactly k/255: cannot use %s texels" % fmt)
         if self.fmt is None:
             self.fmt = _lib.PANO_F32
             self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_F32))

@@ -45,11 +45,14 @@ def test_cloud2idx_golden(ops):
     assert outb.shape == g["coord_b"].shape and np.abs(outb - g["coord_b"]).max() <= 5e-7
 
 
-@pytest.mark.parametrize("fmt", ["auto", "f32"])
+FMT_CODE = {"auto": 2, "f16": 2, "u8": 1, "f32": 0}      # PCL_PANO_*; "auto" picks fp16-level texels for k/255 images
+
+
+@pytest.mark.parametrize("fmt", ["auto", "u8", "f32"])
 def test_sample_from_img_golden(ops, fmt):
     g = load_golden("g2_sample_from_img.npz")
     pano = ops.Pano(T(g["img"]), fmt=fmt)
-    assert pano.fmt == (ops._lib.PANO_U8 if fmt == "auto" else ops._lib.PANO_F32)      # the golden image is k/255
+    assert pano.fmt == FMT_CODE[fmt]                                                 # the golden image is k/255
     out = ops.sample_from_img(pano, T(g["coord"])).cpu().numpy()
     assert np.abs(out - g["rgb"]).max() <= 2e-6
     assert np.array_equal(out == 0, g["rgb"] == 0)          # the exact-zero pattern drives the loss mask
@@ -95,11 +98,11 @@ def _loss(ops, xyz, rgb, img, trans, rot, grad=True, sort=True, fmt="auto"):
     return ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=grad).cpu().numpy()
 
 
-@pytest.mark.parametrize("fmt", ["auto", "f32"])
+@pytest.mark.parametrize("fmt", ["auto", "u8", "f32"])
 @pytest.mark.parametrize("sort", [False, True])
 def test_sampling_loss_golden(ops, sort, fmt):
-    """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run; RGBA8
-    texels (auto: the golden panorama is k/255) and float4 texels."""
+    """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run; fp16-level
+    texels (auto: the golden panorama is k/255), RGBA8 texels and float4 texels."""
     g = load_golden("g3_sampling_loss.npz")
     out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort, fmt=fmt)
     assert rel(out[:, 0], g["loss_f64"]) <= 2e-6
@@ -128,17 +131,23 @@ def test_pano_format_selection_and_float_image(ops, oracle):
     t_gt, ypr_gt = synth.gt_pose(31)
     img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
     img_f = (img * np.float32(0.93)).astype(np.float32)             # same black pattern, values no longer k/255
-    assert ops.Pano(T(img)).fmt == ops._lib.PANO_U8 and ops.Pano(T(img_f)).fmt == ops._lib.PANO_F32
+    assert ops.Pano(T(img)).fmt == ops._lib.PANO_F16 and ops.Pano(T(img_f)).fmt == ops._lib.PANO_F32
+    for f in ("u8", "f16"):
+        with pytest.raises(ValueError):
+            ops.Pano(T(img_f), fmt=f)
     with pytest.raises(ValueError):
-        ops.Pano(T(img_f), fmt="u8")
+        ops.Pano(T(img), fmt="bf16")
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=31)
     out = _loss(ops, xyz, rgb, img_f, trans, rot)
     ref = oracle.sampling_loss(xyz, rgb, img_f, trans, rot, dtype=np.float64)
     assert np.abs(out[:, 1] - ref["count"]).max() <= 2
     assert rel(out[:, 0], ref["loss"]) <= 1e-5
     assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
-    # and the two texel formats agree with each other on a k/255 image (same taps, different rounding of the lerp)
-    a, b = _loss(ops, xyz, rgb, img, trans, rot, fmt="auto"), _loss(ops, xyz, rgb, img, trans, rot, fmt="f32")
+    # the texel formats agree with each other on a k/255 image: fp16-level and RGBA8 texels bit for bit (same real
+    # operands into the same fp32 fmas), float4 texels up to the rounding of the lerp
+    a, b = _loss(ops, xyz, rgb, img, trans, rot, fmt="f16"), _loss(ops, xyz, rgb, img, trans, rot, fmt="f32")
+    u = _loss(ops, xyz, rgb, img, trans, rot, fmt="u8")
+    assert np.array_equal(a.view(np.uint32), u.view(np.uint32))
     assert np.array_equal(a[:, 1], b[:, 1]) and rel(a[:, 0], b[:, 0]) <= 1e-6 and rel(a[:, 2:], b[:, 2:]) <= 1e-4
 
 
