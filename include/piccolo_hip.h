@@ -42,20 +42,23 @@ const char *pcl_error_string(int code);
  *         neighbouring texels (the loss is a sum over points, so the order does not change the result beyond
  *         fp32 summation rounding).
  * pano  : the query image (H,W,3) float (localize.py:167-170) repacked as (H+2, W+2) texels with a one-texel zero
- *         border, so grid_sample's zero padding (utils.py:98) needs no bounds test.  Two texel formats:
+ *         border, so grid_sample's zero padding (utils.py:98) needs no bounds test.  Three texel formats:
  *           PCL_PANO_F32 : RGBA float4, 16 B/texel — any float image;
  *           PCL_PANO_U8  : RGBA8, 4 B/texel — for images whose every value is exactly k/255 in fp32, which is what
  *                          the reference always feeds (cv2.imread -> uint8 -> .float() / 255., localize.py:167-170,
  *                          211-213; color_mod also re-quantises to uint8, color_utils.py:48-50).  A 2x2 bilinear
  *                          footprint is then two 8-byte loads and the whole panorama is 4x smaller, so the gathers
  *                          stay in L2.  The kernel interpolates the integer levels and scales by 1/255 once.
- *         pcl_pano_pack_u8 sets *not_exact (device int, caller zeroes it) if some value is NOT exactly k/255: the
- *         caller must then fall back to PCL_PANO_F32.
+ *           PCL_PANO_F16 : RGBA half4, 8 B/texel — the same k/255 images with the levels 0..255 held as fp16 (exact).
+ *                          A footprint is two 16-byte loads; the tap differences are exact fp16 and the lerps read
+ *                          fp16 operands directly (v_fma_mix_f32), so no tap is converted: same results as PCL_PANO_U8
+ *                          bit for bit, loss kernel 4-5 % faster, twice the texture bytes (still L2/MALL resident).
+ *         pcl_pano_pack_u8 / _f16 set *not_exact (device int, caller zeroes it) if some value is NOT exactly k/255:
+ *         the caller must then fall back to PCL_PANO_F32.
  */
 #define PCL_PANO_F32 0
 #define PCL_PANO_U8 1
-#define PCL_PANO_F16 2 /* RGBA half4, 8 B/texel, levels 0..255 held as fp16 (same k/255 images as PCL_PANO_U8; packed by
-                        * pcl_pano_pack_f16): the loss kernel reads the taps with mixed-precision fma, no byte converts */
+#define PCL_PANO_F16 2
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
