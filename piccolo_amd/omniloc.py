@@ -160,6 +160,8 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
     B = int(input_trans_list[0].shape[0])
     cloud = packed_cloud(xyz, rgb)
     panos = [packed_pano(im) if I <= 8 else ops.Pano(im) for im in imgs]
+    if len({p.fmt for p in panos}) > 1:          # a launch needs ONE texel format: float4 holds any image
+        panos = [ops.Pano(im, fmt="f32") for im in imgs]
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
     box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
     tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])

@@ -128,6 +128,12 @@ def test_omniloc_batch_images_equals_per_image_calls(oracle):
     multi = po.omniloc_batch_images(imgs, X, C, [t.clone() for t in trs], [r.clone() for r in ros], cfg)
     for a, b in zip(single, multi):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # one image that is not k/255 forces a common texel format (float4) for the whole launch: still one result per image,
+    # the k/255 images within the lerp-rounding distance of their level-texel results
+    mixed = [imgs[0], imgs[1] * 0.9, imgs[2]]
+    out = po.omniloc_batch_images(mixed, X, C, [t.clone() for t in trs], [r.clone() for r in ros], cfg)
+    assert len(out) == I and all(torch.isfinite(o[2]) for o in out)
+    assert abs(float(out[0][2]) - float(single[0][2])) <= 1e-4 * abs(float(single[0][2])) + 1e-6
 
 
 def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
