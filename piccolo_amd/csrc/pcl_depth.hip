@@ -153,8 +153,9 @@ int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses
     static const bool direct = getenv("PCL_ZPASS_DIRECT") != nullptr;       // A/B knob: the untiled scatter
     if (direct) hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a);
     else {
-        // 64 x 128 window, 2048 points per block: best of {32..128} x {64,128} x {1024..4096} at cfg 2 (276 us; 288-374 us
-        // for the others; the direct scatter takes 616 us)
+        // 64 x 128 window, 2048 points per block: best of {32..128} x {64,128} x {256..4096} at cfg 2 (276 us; 288-374 us
+        // for the others, 2x slower at 256 points per block — one pixel per point here, unlike the 3x3 splats of
+        // pcl_hist.hip where 256 wins; the direct scatter takes 616 us)
         constexpr int TH = 64, TW = 128, PTS = 2048;
         hipLaunchKernelGGL((pcl_zpass_tiled_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)B),
                            dim3(PCL_BLOCK), 0, s, a);

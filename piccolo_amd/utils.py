@@ -106,7 +106,7 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     """Keep the `num_input` (translation, rotation) pairs with the smallest sampling loss out of all K x R pairs.
     The reference loops K*R forwards in Python (utils.py:484-499); here all pairs go through one fused launch."""
     K, Rn = len(trans), len(rot)
-    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
+    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img, many_poses=True)
     tt = ops._dev(trans).repeat_interleave(Rn, dim=0)
     rr = ops._dev(rot).repeat(K, 1)
     table = ops.sampling_loss(cloud, pano, tt, rr, with_grad=False)[:, 0]          # row-major (K, R) like loss_table
