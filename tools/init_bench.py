@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wall time of the initialisation stage (make_input: candidate grid -> sampling-loss trim -> histogram trim) and of the
-refinement, per query image, on one GPU.   python tools/init_bench.py [n_points H W]"""
+refinement, per query image, on one GPU.   python tools/init_bench.py [n_points H W num_input num_intermediate]
+(the reference's stanford_parallel.ini is 1M/6 points, 1024 2048, 6, 50)"""
 import os
 import sys
 import time
@@ -15,6 +16,8 @@ from piccolo_amd import ops, synth, utils  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+NUM_INPUT = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+NUM_INTER = int(sys.argv[5]) if len(sys.argv) > 5 else 64
 dev = torch.device("cuda:0")
 xyz, rgb = synth.box_room(n, 0)
 X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
@@ -27,7 +30,7 @@ init = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_
 
 
 class Cfg:
-    lr, num_iter, patience, factor, out_of_room_quantile, num_input = 0.1, 100, 5, 0.8, 0.05, 32
+    lr, num_iter, patience, factor, out_of_room_quantile, num_input = 0.1, 100, 5, 0.8, 0.05, NUM_INPUT
 
 
 def sync():
@@ -39,11 +42,11 @@ for rep in range(3):
     rot = utils.generate_rot_points(init, device=dev)
     trans = utils.generate_trans_points(X, init, device=dev)
     sync(); t1 = time.perf_counter()
-    tt, tr = utils.trim_input_loss(img, X, C, trans, rot, 64)
+    tt, tr = utils.trim_input_loss(img, X, C, trans, rot, NUM_INTER)
     sync(); t2 = time.perf_counter()
-    it, ir = utils.trim_input_hist_secondary(img, X, C, tt, tr, 32, 4, 4)
+    it, ir = utils.trim_input_hist_secondary(img, X, C, tt, tr, NUM_INPUT, 4, 4)
     sync(); t3 = time.perf_counter()
-    it2, ir2 = utils.make_input(img, X, C, 32, init, "loss_histogram", 64)
+    it2, ir2 = utils.make_input(img, X, C, NUM_INPUT, init, "loss_histogram", NUM_INTER)
     sync(); t3b = time.perf_counter()
     assert torch.equal(it, it2) and torch.equal(ir, ir2)
     make_input_ms = (t3b - t3) * 1e3
