@@ -84,12 +84,15 @@ class Pano:
             raise ValueError("img must be (H, W, 3)")
         self.H, self.W = int(img.shape[0]), int(img.shape[1])
         self.fmt = None
-        if fmt == "auto":
-            fmt = os.environ.get("PCL_PANO_FMT", "auto")      # experiments: force a texel format
         if fmt not in ("auto", "f16", "u8", "f32"):
             raise ValueError("unknown texel format %r" % (fmt,))
+        prefer = "f16"
+        if fmt == "auto":                                     # experiments: PCL_PANO_FMT = what "auto" tries first
+            prefer = os.environ.get("PCL_PANO_FMT", "f16")
+            if prefer == "f32":
+                fmt = "f32"
         if fmt != "f32":
-            fn, code = self._PACK["f16" if fmt == "auto" else fmt]
+            fn, code = self._PACK[prefer if fmt == "auto" else fmt]
             data = _bytes(lib.pcl_pano_bytes(self.H, self.W, code))
             flag = torch.zeros(1, dtype=torch.int32, device=img.device)
             _lib.check(getattr(lib, fn)(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), fn)
