@@ -205,7 +205,8 @@ def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, r
                     writer.add_text("failed rooms", filenames[k])
                 total += 1
                 accuracy = well_posed / total
-                scalar_summaries["current_accuracy"].append(accuracy)
+                scalar_summaries["current_accuracy"] = [accuracy]
+                write_summaries(writer, scalar_summaries, k)                     # localize.py:295
                 w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 0, _fmt(row[0:3]), _fmt(row[3:12]), t_err, r_err,
                                                        float(row[15])])
         writer.add_scalar("final accuracy", accuracy)

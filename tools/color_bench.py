@@ -11,7 +11,6 @@ Algorithmic bytes (fp32 HWC / (n,3) tensors, every pass counted once):
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
