@@ -19,7 +19,7 @@ from . import dist as pdist
 from . import ops, synth
 from .color_utils import color_match, color_mod
 from .omniloc import omniloc_all, omniloc_batch
-from .utils import make_input, make_pano, out_of_room, write_summaries
+from .utils import make_input, make_pano, out_of_room, resize_image, write_summaries
 
 
 def preprocess_colors(img, rgb, cfg):
@@ -113,26 +113,6 @@ def read_image(filename):
     from PIL import Image
     with Image.open(filename) as im:
         return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
-
-
-def resize_image(img8, width, height):
-    """uint8 (H,W,3) -> (height,width,3), bilinear with OpenCV's INTER_LINEAR geometry (pixel centres at k + 0.5, edge
-    clamp, no antialiasing; cv2.resize at localize.py:168,211,372).  Identity when the size is unchanged, which is the
-    case for all shipped configs on 2048 x 1024 panoramas.  cv2 interpolates in 11-bit fixed point: results may differ
-    from it by one level — parity unpinned (OpenCV is absent from the build image)."""
-    H, W = img8.shape[:2]
-    if (W, H) == (width, height):
-        return img8
-    fy = (np.arange(height, dtype=np.float64) + 0.5) * (H / height) - 0.5
-    fx = (np.arange(width, dtype=np.float64) + 0.5) * (W / width) - 0.5
-    y0, x0 = np.floor(fy).astype(np.int64), np.floor(fx).astype(np.int64)
-    wy, wx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
-    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
-    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
-    a = img8.astype(np.float64)
-    top = a[y0c][:, x0c] * (1 - wx) + a[y0c][:, x1c] * wx
-    bot = a[y1c][:, x0c] * (1 - wx) + a[y1c][:, x1c] * wx
-    return np.clip(np.rint(top * (1 - wy) + bot * wy), 0, 255).astype(np.uint8)
 
 
 def _to_img(img8, dev):

@@ -21,7 +21,7 @@ from .omniloc import packed_cloud, packed_pano
 
 __all__ = ["cloud2idx", "sample_from_img", "warp_from_img", "reshape_img_tensor", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
            "trim_input_hist_secondary", "make_input", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
-           "compute_sampling_grid", "create_coordinate", "write_summaries", "get_bound", "defaultdict", "torch", "np"]
+           "compute_sampling_grid", "create_coordinate", "write_summaries", "resize_image", "get_bound", "defaultdict", "torch", "np"]
 
 
 def _like(out, ref):
@@ -55,9 +55,32 @@ def warp_from_img(img, coord_arr, padding="zeros", mode="bilinear"):
     return sample_from_img(img, coord_arr.reshape(-1, 2)).reshape(shp[0], shp[1], 3)
 
 
+def resize_image(img8, width, height):
+    """uint8 (H,W,3) -> (height,width,3), bilinear with OpenCV's INTER_LINEAR geometry (pixel centres at k + 0.5, edge
+    clamp, no antialiasing; cv2.resize at localize.py:168,211,372).  Identity when the size is unchanged, which is the
+    case for all shipped configs on 2048 x 1024 panoramas.  cv2 interpolates in 11-bit fixed point: results may differ
+    from it by one level — parity unpinned (OpenCV is absent from the build image)."""
+    H, W = img8.shape[:2]
+    if (W, H) == (width, height):
+        return img8
+    fy = (np.arange(height, dtype=np.float64) + 0.5) * (H / height) - 0.5
+    fx = (np.arange(width, dtype=np.float64) + 0.5) * (W / width) - 0.5
+    y0, x0 = np.floor(fy).astype(np.int64), np.floor(fx).astype(np.int64)
+    wy, wx = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+    y0c, y1c = np.clip(y0, 0, H - 1), np.clip(y0 + 1, 0, H - 1)
+    x0c, x1c = np.clip(x0, 0, W - 1), np.clip(x0 + 1, 0, W - 1)
+    a = img8.astype(np.float64)
+    top = a[y0c][:, x0c] * (1 - wx) + a[y0c][:, x1c] * wx
+    bot = a[y1c][:, x0c] * (1 - wx) + a[y1c][:, x1c] * wx
+    return np.clip(np.rint(top * (1 - wy) + bot * wy), 0, 255).astype(np.uint8)
+
+
 def reshape_img_tensor(img, size):
-    raise NotImplementedError("reshape_img_tensor resizes through cv2 on the host (utils.py:632-638): not part of the "
-                              "GPU path; resize the image before handing it over")
+    """utils.py:632-638: (H,W,3) float image in [0,1] -> uint8 -> resized to size = (X, Y) -> float / 255, on img's device
+    (host round trip like the reference; `resize_image` stands in for cv2.resize)."""
+    cv_img = (img.detach().cpu().numpy() * 255).astype(np.uint8)
+    cv_img = resize_image(cv_img, int(size[0]), int(size[1])) / 255.
+    return torch.from_numpy(cv_img).float().to(img.device)
 
 
 def rot_from_ypr(ypr_array):

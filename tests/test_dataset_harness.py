@@ -134,7 +134,7 @@ def test_localize_omniscenes_layout(tmp_path):
 
 
 def test_resize_image_geometry():
-    from piccolo_amd.localize import resize_image
+    from piccolo_amd.utils import resize_image
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (8, 16, 3)).astype(np.uint8)
     assert resize_image(img, 16, 8) is img

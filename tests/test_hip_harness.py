@@ -207,5 +207,6 @@ def test_warp_from_img_matches_golden_samples():
     coord = torch.from_numpy(g["coord"][:1200].reshape(30, 40, 2)).cuda()
     out = utils.warp_from_img(torch.from_numpy(g["img"]).cuda(), coord).cpu().numpy()
     assert out.shape == (30, 40, 3) and np.abs(out.reshape(-1, 3) - g["rgb"][:1200]).max() <= 2e-6
-    with pytest.raises(NotImplementedError):
-        utils.reshape_img_tensor(torch.zeros(4, 4, 3), (2, 2))
+    # reshape_img_tensor (utils.py:632-638): uint8 round trip + bilinear resize to size = (X, Y), on the input's device
+    small = utils.reshape_img_tensor(torch.full((4, 8, 3), 0.5), (4, 2))
+    assert tuple(small.shape) == (2, 4, 3) and torch.allclose(small, torch.full((2, 4, 3), 127 / 255.))
