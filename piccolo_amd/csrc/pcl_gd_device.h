@@ -42,64 +42,87 @@ __device__ __forceinline__ void pcl_chain_rule(const double s[PCL_NACC], const f
 }
 
 // One wave (`lane` = 0..63) finishes pose b: deterministic reduction, chain rule, Adam, plateau scheduler, clamp, next
-// pose record.
+// pose record.  The per-parameter work runs lane-parallel — lane k < 6 owns parameter k (t0, t1, t2, yaw, pitch, roll):
+// its gradient component, its Adam update, its clamp; lanes 3..5 take the sin/cos of the three angles at once — because
+// a single lane walking through six updates and three sincosf was a 5 us dependent instruction chain per iteration.
+// Every element goes through exactly the operations it went through in the one-lane form (bit-identical results).
 __device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ partials, int nchunks, int B, int b, int lane, PclGdPose* st,
                                           PclPoseRec* recs, const float* __restrict__ box, double factor, int patience, int mode,
                                           float* loss_out)
 {
+    // torch evaluates the optimiser with separate, individually rounded tensor operations: no fused multiply-adds here
+#pragma clang fp contract(off)
     double s[PCL_NACC];
-    pcl_reduce_partials(partials, nchunks, B, b, lane, s);
-    if (lane != 0) return;
-    PclGdPose g = st[b];
-    float loss, grad[6];
-    pcl_chain_rule(s, recs[b].R, g.sc[0], g.sc[1], g.sc[2], g.sc[3], loss, grad);
-    g.last_loss = loss;
-    if (loss_out) loss_out[b] = loss;
+    pcl_reduce_partials(partials, nchunks, B, b, lane, s);      // every lane holds the eight sums
+    PclGdPose* gp = st + b;
+    PclPoseRec* rec = recs + b;
+    const bool owner = lane < 6;
+    const int k = owner ? lane : 0;
+
+    // loss and this lane's gradient component (pcl_chain_rule, one component per lane)
+    const double M = s[1];
+    const float loss = (float)s[0] / (float)M;
+    const double inv = 1.0 / M;
+    const double sy = gp->sc[0], cy = gp->sc[1], sp = gp->sc[2], cp = gp->sc[3];
+    float gk;
+    if (k < 3) gk = (float)(-((double)rec->R[k] * s[2] + (double)rec->R[3 + k] * s[3] + (double)rec->R[6 + k] * s[4]) * inv);
+    else if (k == 3) gk = (float)(s[7] * inv);
+    else if (k == 4) gk = (float)((-sy * s[5] + cy * s[6]) * inv);
+    else gk = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
 
     // torch.optim.Adam, single-tensor form (betas 0.9/0.999, eps 1e-8; call sites omniloc.py:33,235-236):
     // fp32 tensor math, python-double scalars
     const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-    g.step += 1;
-    g.beta1_pow *= beta1;                                     // beta ** step as a running product (python: pow)
-    g.beta2_pow *= beta2;
-    double bc1 = 1.0 - g.beta1_pow;
-    double bc2 = 1.0 - g.beta2_pow;
-    float step_size = (float)(-(g.lr / bc1));
-    float bc2_sqrt = (float)sqrt(bc2);
+    double lr = gp->lr, best = gp->best;
+    int num_bad = gp->num_bad;
+    const int step = gp->step + 1;
+    const double beta1_pow = gp->beta1_pow * beta1;             // beta ** step as a running product (python: pow)
+    const double beta2_pow = gp->beta2_pow * beta2;
+    const double bc1 = 1.0 - beta1_pow;
+    const double bc2 = 1.0 - beta2_pow;
+    const float step_size = (float)(-(lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        float gk = grad[k];
-        g.m[k] = g.m[k] + w1 * (gk - g.m[k]);                 // exp_avg.lerp_(grad, 1 - beta1)
-        g.v[k] = g.v[k] * b2 + w2 * gk * gk;                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        float denom = sqrtf(g.v[k]) / bc2_sqrt + (float)eps;  // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
-        g.leaf[k] = g.leaf[k] + step_size * g.m[k] / denom;   // param.addcdiv_(exp_avg, denom, value=-step_size)
-    }
+    float m = gp->m[k], v = gp->v[k], leaf = gp->leaf[k];
+    m = m + w1 * (gk - m);                                      // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + w2 * gk * gk;                                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + (float)eps;       // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    leaf = leaf + step_size * m / denom;                        // param.addcdiv_(exp_avg, denom, value=-step_size)
 
     // ReduceLROnPlateau(mode='min', threshold=1e-4 rel, cooldown=0, min_lr=0, eps=1e-8).step(float(loss))
-    // (omniloc.py:37,50 / :237,258)
-    double cur = (double)loss;
-    if (cur < g.best * (1.0 - 1e-4)) { g.best = cur; g.num_bad = 0; }
-    else g.num_bad += 1;
-    if (g.num_bad > patience) {
-        double new_lr = g.lr * factor;
+    // (omniloc.py:37,50 / :237,258) — wave-uniform
+    const double cur = (double)loss;
+    if (cur < best * (1.0 - 1e-4)) { best = cur; num_bad = 0; }
+    else num_bad += 1;
+    if (num_bad > patience) {
+        double new_lr = lr * factor;
         if (new_lr < 0.0) new_lr = 0.0;
-        if (g.lr - new_lr > 1e-8) g.lr = new_lr;
-        g.num_bad = 0;
+        if (lr - new_lr > 1e-8) lr = new_lr;
+        num_bad = 0;
     }
 
     // clamp t to the quantile box; batch mode forwards the pre-clamp copy (omniloc.py:260-269), sequential mode
     // clamps the very tensor the next forward reads (omniloc.py:56-58)
-    if (mode == PCL_GD_BATCH) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    float fwd = leaf;
+    if (k < 3) leaf = fminf(fmaxf(leaf, box[2 * k]), box[2 * k + 1]);
+    if (mode != PCL_GD_BATCH) fwd = leaf;
+
+    // next pose record: lanes 3..5 hold yaw, pitch, roll (same fp32 sincosf + double products as pcl_write_pose_rec_fast)
+    float sn, cs;
+    sincosf(fwd, &sn, &cs);
+    const double dsy = __shfl(sn, 3, 64), dcy = __shfl(cs, 3, 64), dsp = __shfl(sn, 4, 64), dcp = __shfl(cs, 4, 64);
+    const double dsr = __shfl(sn, 5, 64), dcr = __shfl(cs, 5, 64);
+    if (owner) {
+        gp->leaf[k] = leaf; gp->fwd[k] = fwd; gp->m[k] = m; gp->v[k] = v;
+        if (k < 3) rec->t[k] = fwd;                             // (pano_lo / pano_hi are left as they are)
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) g.leaf[k] = fminf(fmaxf(g.leaf[k], box[2 * k]), box[2 * k + 1]);
-    if (mode != PCL_GD_BATCH) {
-#pragma unroll
-        for (int k = 0; k < 6; k++) g.fwd[k] = g.leaf[k];
+    if (lane == 0) {
+        rec->R[0] = (float)(dcy * dcp); rec->R[1] = (float)(dcy * dsp * dsr - dsy * dcr); rec->R[2] = (float)(dcy * dsp * dcr + dsy * dsr);
+        rec->R[3] = (float)(dsy * dcp); rec->R[4] = (float)(dsy * dsp * dsr + dcy * dcr); rec->R[5] = (float)(dsy * dsp * dcr - dcy * dsr);
+        rec->R[6] = (float)(-dsp);      rec->R[7] = (float)(dcp * dsr);                   rec->R[8] = (float)(dcp * dcr);
+        gp->sc[0] = (float)dsy; gp->sc[1] = (float)dcy; gp->sc[2] = (float)dsp; gp->sc[3] = (float)dcp;
+        gp->lr = lr; gp->best = best; gp->num_bad = num_bad; gp->step = step;
+        gp->beta1_pow = beta1_pow; gp->beta2_pow = beta2_pow; gp->last_loss = loss;
+        if (loss_out) loss_out[b] = loss;
     }
-    pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
-    st[b] = g;
 }
