@@ -6,8 +6,9 @@
  * (file:line relative to the reference checkout).
  *
  * Conventions
- *  - every pointer is a DEVICE pointer unless its name ends in _host; all buffers are caller-owned, the library
- *    never allocates, frees or synchronises (graph-capture safe); `stream` is a hipStream_t passed as void*;
+ *  - every pointer is a DEVICE pointer unless its name ends in _host; all buffers are caller-owned, the device entry
+ *    points never allocate, free or synchronise (graph-capture safe); `stream` is a hipStream_t passed as void*;
+ *    the dataset text reader (pcl_cloud_txt_*) is host-only code and takes host pointers;
  *  - every function returns 0 on success, a hipError_t value (> 0) for a runtime failure, or one of the
  *    negative PCL_E* codes below for a bad argument;
  *  - fp32 throughout, like the reference (localize.py:159-170); poses are (t[3], yaw, pitch, roll) with
@@ -23,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 1
+#define PCL_ABI_VERSION 2 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */

@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
