@@ -63,6 +63,10 @@ const char *pcl_error_string(int code);
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
+/* The Morton order in one call, entirely on the device: bounding box, 63-bit keys, stable radix sort of (key, index);
+ * order[i] = index of the point for packed slot i.  workspace: pcl_cloud_order_workspace_bytes(n). */
+size_t pcl_cloud_order_workspace_bytes(int64_t n);
+int pcl_cloud_order(const float *xyz, int64_t n, int64_t *order, void *workspace, size_t workspace_bytes, void *stream);
 /* 63-bit Morton keys of xyz quantised to 21 bits per axis inside [lo, hi] (host arrays of 3); sort them to get `order`. */
 int pcl_morton_keys(const float *xyz, int64_t n, const float *lo_host, const float *hi_host, int64_t *keys, void *stream);
 

@@ -33,6 +33,8 @@ SIGNATURES = {
     "pcl_morton_keys": (_int, [_vp, _i64, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float), _vp, _vp]),
     "pcl_pano_bytes": (_sz, [_int, _int, _int]),
     "pcl_pano_pack": (_int, [_vp, _int, _int, _vp, _vp]),
+    "pcl_cloud_order_workspace_bytes": (_sz, [_i64]),
+    "pcl_cloud_order": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "pcl_pano_pack_u8": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_pano_pack_f16": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),

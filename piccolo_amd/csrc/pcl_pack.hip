@@ -3,6 +3,8 @@
 //   pano  : (H,W,3) float image              (localize.py:167-170)  -> zero-bordered (H+2, W+2) RGBA float4
 #include "pcl_device.h"
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 extern "C" int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 
 extern "C" const char* pcl_error_string(int code)
@@ -83,6 +85,97 @@ extern "C" int pcl_morton_keys(const float* xyz, int64_t n, const float* lo, con
                        (hipStream_t)stream, xyz, n, lo[0], lo[1], lo[2], s[0], s[1], s[2], keys);
     PCL_LAUNCH_CHECK();
     return 0;
+}
+
+// ---- Morton order of a cloud, entirely on the device: bounding box -> 63-bit keys -> radix sort of (key, index) pairs.
+// workspace: [box: 6 ordered-uint words][keys n][keys sorted n][iota n][rocPRIM temp]
+__device__ __forceinline__ unsigned int pcl_ordered_key(float v)
+{
+    unsigned int b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float pcl_ordered_value(unsigned int k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_bbox_kernel(const float* __restrict__ xyz, int64_t n, unsigned int* __restrict__ box)
+{
+    unsigned int lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            unsigned int k = pcl_ordered_key(xyz[3 * i + c]);
+            lo[c] = min(lo[c], k); hi[c] = max(hi[c], k);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[c] = min(lo[c], (unsigned int)__shfl_xor((int)lo[c], o, 64));
+            hi[c] = max(hi[c], (unsigned int)__shfl_xor((int)hi[c], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&box[c], lo[c]); atomicMax(&box[3 + c], hi[c]); }
+    }
+}
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_morton_box_kernel(const float* __restrict__ xyz, int64_t n, const unsigned int* __restrict__ box,
+                                                                   unsigned long long* __restrict__ keys, int64_t* __restrict__ iota)
+{
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float top = 2097151.f;  // 2^21 - 1
+    unsigned long long k = 0ull;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float lo = pcl_ordered_value(box[c]), hi = pcl_ordered_value(box[3 + c]);
+        float sc = hi > lo ? top / (hi - lo) : 0.f;
+        float f = __builtin_amdgcn_fmed3f((xyz[3 * i + c] - lo) * sc, 0.f, top);
+        k |= pcl_spread21((uint32_t)f) << c;
+    }
+    keys[i] = k;
+    iota[i] = i;
+}
+
+static size_t order_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t order_sort_temp_bytes(int64_t n)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned long long*, unsigned long long*, const int64_t*, int64_t*>(
+        nullptr, bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, 63, nullptr, false);
+    return bytes;
+}
+
+extern "C" size_t pcl_cloud_order_workspace_bytes(int64_t n)
+{
+    if (n <= 0) return 0;
+    return order_align(64) + 3 * order_align((size_t)n * 8) + order_align(order_sort_temp_bytes(n));
+}
+
+// order[i] = index of the point that goes to packed slot i (Morton order of xyz inside its bounding box); feed it to
+// pcl_cloud_pack.  Equal keys keep their original relative order (stable LSD radix sort).
+extern "C" int pcl_cloud_order(const float* xyz, int64_t n, int64_t* order, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!xyz || !order || !workspace || n <= 0 || n > ((int64_t)1 << 27)) return PCL_EINVAL;
+    if (workspace_bytes < pcl_cloud_order_workspace_bytes(n)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    unsigned int* box = (unsigned int*)ws; ws += order_align(64);
+    unsigned long long* keys = (unsigned long long*)ws; ws += order_align((size_t)n * 8);
+    unsigned long long* keys_sorted = (unsigned long long*)ws; ws += order_align((size_t)n * 8);
+    int64_t* iota = (int64_t*)ws; ws += order_align((size_t)n * 8);
+    hipError_t e = hipMemsetAsync(box, 0xff, 12, s);                          // lo = max key
+    if (e == hipSuccess) e = hipMemsetAsync(box + 3, 0, 12, s);               // hi = min key
+    if (e != hipSuccess) return (int)e;
+    int64_t blocks = (n + PCL_BLOCK - 1) / PCL_BLOCK;
+    hipLaunchKernelGGL(pcl_bbox_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(PCL_BLOCK), 0, s, xyz, n, box);
+    hipLaunchKernelGGL(pcl_morton_box_kernel, dim3((unsigned)blocks), dim3(PCL_BLOCK), 0, s, xyz, n, box, keys, iota);
+    PCL_LAUNCH_CHECK();
+    size_t temp_bytes = order_sort_temp_bytes(n);
+    e = rocprim::radix_sort_pairs(ws, temp_bytes, (const unsigned long long*)keys, keys_sorted, (const int64_t*)iota, order, (size_t)n, 0, 63,
+                                  s, false);
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_kernel(const float* __restrict__ img, int H, int W,

@@ -54,13 +54,10 @@ class Cloud:
             raise ValueError("empty point cloud")
         self.order = None
         if sort and self.n > 1:
-            lo = xyz.min(0).values.cpu()
-            hi = xyz.max(0).values.cpu()
-            keys = torch.empty(self.n, dtype=torch.int64, device=xyz.device)
-            lo_c = (ctypes.c_float * 3)(*[float(v) for v in lo])
-            hi_c = (ctypes.c_float * 3)(*[float(v) for v in hi])
-            _lib.check(lib.pcl_morton_keys(_ptr(xyz), self.n, lo_c, hi_c, _ptr(keys), _stream()), "pcl_morton_keys")
-            self.order = torch.argsort(keys)   # plumbing: one-time reordering of the cloud
+            self.order = torch.empty(self.n, dtype=torch.int64, device=xyz.device)
+            nws = lib.pcl_cloud_order_workspace_bytes(self.n)
+            ws = _bytes(nws)
+            _lib.check(lib.pcl_cloud_order(_ptr(xyz), self.n, _ptr(self.order), _ptr(ws), nws, _stream()), "pcl_cloud_order")
         self.data = _bytes(lib.pcl_cloud_bytes(self.n))
         _lib.check(lib.pcl_cloud_pack(_ptr(xyz), _ptr(rgb), _ptr(self.order), self.n, _ptr(self.data), _stream()),
                    "pcl_cloud_pack")

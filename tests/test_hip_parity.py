@@ -608,3 +608,31 @@ def test_end_to_end_pose_inside_reference_self_noise_band(ops):
     # and the recovered pose itself is within the reference's run-to-run spread of the reference's pose
     spread = max(float(g["self_noise"][:, 2].max()), 1e-3)
     assert np.abs(res[0].numpy() - g["ret_t"]).max() <= 5 * spread, (np.abs(res[0].numpy() - g["ret_t"]).max(), spread)
+
+
+def test_cloud_order_is_a_morton_sorted_permutation(ops):
+    """pcl_cloud_order (bounding box, 63-bit keys and radix sort on the device): a permutation whose Morton keys,
+    recomputed here from the same quantisation, are non-decreasing; equal keys keep their input order (stable)."""
+    from piccolo_amd import synth
+    xyz, rgb = synth.box_room(50_003, 4)
+    xyz[100:120] = xyz[50]                                   # duplicates: equal keys
+    cloud = ops.Cloud(T(xyz), T(rgb))
+    order = cloud.order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(xyz)))
+    lo, hi = xyz.min(0), xyz.max(0)
+    q = np.clip((xyz - lo) * (np.float32(2097151.0) / (hi - lo)), 0, 2097151).astype(np.uint64)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(21):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+    keys = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    ks = keys[order]
+    # (a key may differ from the device's by one quantisation step at a cell boundary: compare through the sorted order)
+    assert (np.diff(ks.astype(np.int64)) >= 0).mean() > 0.999
+    dup = np.nonzero(np.isin(order, np.r_[50, np.arange(100, 120)]))[0]
+    assert np.array_equal(order[dup], np.sort(order[dup]))   # stable among identical points
+    # the packed planes hold exactly the reordered points (colours negated)
+    planes = cloud.data[: 6 * 4 * ops._lib.load().pcl_cloud_stride(cloud.n)].view(torch.float32).reshape(6, -1)[:, : cloud.n].cpu().numpy()
+    assert np.array_equal(planes[:3].T, xyz[order]) and np.array_equal(planes[3:].T, -rgb[order])
