@@ -185,6 +185,10 @@ size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw);
 int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, int H, int W, const float *trans,
                          const float *rot, int ncand, int nsh, int nsw, float *inter, int32_t *nproj, int32_t *nimg,
                          void *workspace, size_t workspace_bytes, void *stream);
+/* score[cand] of the trimming stage from pcl_hist_trim_scores' outputs: sum of the block intersections of every block row
+ * up to its first empty block (utils.py:568-571), divided by nsh * nsw (utils.py:580). */
+int pcl_hist_trim_reduce(const float *inter, const int32_t *nproj, const int32_t *nimg, int ncand, int nsh, int nsw, float *score,
+                         void *stream);
 /* Scatter-min depth mask on the PACKED cloud for B poses (build-defined, off by default in the loss):
  * visible[b][i] = 1 iff point i (packed order) is within (1 + tau) of the nearest point that falls into the same
  * make_pano pixel (utils.py:158-165) of an H x W panorama seen from pose b.  Feeds the `visible` argument of

@@ -240,3 +240,33 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     PCL_LAUNCH_CHECK();
     return 0;
 }
+
+// score[cand] = sum over the block rows of the intersections up to (not including) the first empty block of the row,
+// divided by nsh * nsw: the reference `break`s out of a block row at the first block where the render or the query has no
+// pixel to histogram (utils.py:568-571) and divides by all nsh * nsw blocks (utils.py:580).  One thread per candidate.
+__global__ void pcl_hist_score_kernel(const float* __restrict__ inter, const int* __restrict__ nproj, const int* __restrict__ nimg,
+                                      int ncand, int nsh, int nsw, float* __restrict__ score)
+{
+    int cand = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cand >= ncand) return;
+    const int nblk = (nsh - 2) * nsw;
+    float total = 0.f;
+    for (int h = 0; h < nsh - 2; h++)
+        for (int w = 0; w < nsw; w++) {
+            int j = h * nsw + w;
+            if (nproj[(int64_t)cand * nblk + j] == 0 || nimg[j] == 0) break;
+            float v = inter[(int64_t)cand * nblk + j];
+            total += (v == v) ? v : 0.f;
+        }
+    score[cand] = total / (float)(nsh * nsw);
+}
+
+extern "C" int pcl_hist_trim_reduce(const float* inter, const int32_t* nproj, const int32_t* nimg, int ncand, int nsh, int nsw, float* score,
+                                    void* stream)
+{
+    if (!inter || !nproj || !nimg || !score || ncand <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3((ncand + 255) / 256), dim3(256), 0, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw,
+                       score);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}

@@ -142,12 +142,11 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16)
         _lib.check(lib.pcl_hist_trim_scores(_ptr(cloud.data), cloud.n, _ptr(img), H, W, _ptr(trans[k0:k1]),
                                             _ptr(rot[k0:k1]), k1 - k0, num_split_h, num_split_w, _ptr(inter[k0:k1]),
                                             _ptr(nproj[k0:k1]), _ptr(nimg), _ptr(ws), nws, _stream()), "pcl_hist_trim_scores")
-    # a block with no pixels zeroes the rest of its block row (the reference `break`s there, utils.py:568-571)
-    empty = (nproj == 0) | (nimg == 0).unsqueeze(0)
-    empty = empty.reshape(K, num_split_h - 2, num_split_w)
-    dead = torch.cumsum(empty.to(torch.int32), dim=2) > 0
-    inter = torch.where(dead, torch.zeros((), device=inter.device), torch.nan_to_num(inter.reshape(dead.shape), nan=0.0))
-    return inter.sum(dim=(1, 2)) / float(num_split_h * num_split_w)
+    # a block with no pixels ends its block row (the reference `break`s there, utils.py:568-571)
+    scores = torch.empty(K, dtype=F32, device=img.device)
+    _lib.check(lib.pcl_hist_trim_reduce(_ptr(inter), _ptr(nproj), _ptr(nimg), K, num_split_h, num_split_w, _ptr(scores), _stream()),
+               "pcl_hist_trim_reduce")
+    return scores
 
 
 def depth_mask(cloud, trans, rot, resolution, tau=0.02):
