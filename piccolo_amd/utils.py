@@ -134,7 +134,9 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     rr = ops._dev(rot).repeat(K, 1)
     table = ops.sampling_loss(cloud, pano, tt, rr, with_grad=False)[:, 0]          # row-major (K, R) like loss_table
     num_input = min(num_input, K * Rn)
-    min_inds = torch.argsort(table)[:num_input].to(trans.device)
+    # loss_table.argsort()[:num_input] (utils.py:500-501); topk is one selection kernel where argsort of a few thousand
+    # values runs ~100 tiny merge-sort launches (1 ms per image); NaN losses (nothing sampled) rank last in both
+    min_inds = torch.topk(table, num_input, largest=False, sorted=True).indices.to(trans.device)
     return trans[torch.div(min_inds, Rn, rounding_mode="floor")], rot[min_inds % Rn]
 
 
@@ -143,7 +145,7 @@ def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h,
     block-wise colour-histogram intersection with the query image.  All candidates go through three fused kernels
     (csrc/pcl_hist.hip): batched z-buffer splat, query histograms, per-(candidate, block) LDS histogram + intersection."""
     scores = ops.hist_trim_scores(img, packed_cloud(xyz, rgb), trans, rot, num_split_h, num_split_w)
-    order = torch.argsort(scores)[-num_input:].flip(0).to(trans.device)
+    order = torch.topk(scores, min(num_input, scores.numel()), largest=True, sorted=True).indices.to(trans.device)   # best first
     return trans[order], rot[order]
 
 
