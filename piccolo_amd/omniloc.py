@@ -164,8 +164,9 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
 
     imgs: list of (H,W,3) images of one size; input_trans_list / input_rot_list: per image (B,3) starting poses (same B).
     The I * B candidates run through one chain of launches (shared cloud in L2, per-candidate panorama pointer), each with
-    its own Adam / scheduler state, so every image gets exactly the result omniloc_batch would give it; at 32 candidates
-    per image, 8 images per launch are ~15 % faster than 8 separate refinements.  Returns a list of [t, R, loss]."""
+    its own Adam / scheduler state, so every image gets the result omniloc_batch would give it (bit for bit when the
+    cloud is cut into the same chunks, else up to the summation order of the partial sums); at 32 candidates per image,
+    8 images per launch are ~25 % faster than 8 separate refinements.  Returns a list of [t, R, loss]."""
     if strict_reference_asserts:
         assert cfg.num_input > 1
     I = len(imgs)
