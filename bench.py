@@ -229,6 +229,9 @@ def main():
     for gi in range(n_warm_groups):
         refine(gi)
     join_streams()
+    if dist is not None:                                       # first use of the collective sets up its connections: untimed
+        src = results if backend == "nccl" else results.cpu()
+        dist.all_gather_into_tensor(torch.empty(world * n_img, 16, device=src.device), src)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -297,6 +300,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit — after Python's own output; flush it
+        # now so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
 
 
