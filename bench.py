@@ -296,17 +296,18 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(xyz, rgb, img0_host, start0_host[0], start0_host[1])
+    # RCCL prints its version banner through C stdio, which is flushed at exit — after Python's own output.  Every rank
+    # flushes it now, before the last barrier, so that rank 0's JSON line is the last thing the job writes to stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL prints its version banner through C stdio, which is flushed at exit — after Python's own output; flush it
-        # now so that the JSON line is the last thing on stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
         print(json.dumps(line), flush=True)
 
 
