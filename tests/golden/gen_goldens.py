@@ -572,10 +572,29 @@ def g15_data_utils():
     save("g15_data_utils.npz", **out)
 
 
+def g16_histogram():
+    """color_utils.histogram / histogram_intersection (pure torch): unit-range and 0..255 images, [32,32,32] (default),
+    [8,8,8] and uneven bins, unbatched and batched forms."""
+    import color_utils as ref_color
+    rng = np.random.default_rng(16)
+    img255 = rng.integers(0, 256, size=(2, 20, 30, 3)).astype(np.float32)
+    mask = rng.random((2, 20, 30)) < 0.6
+    out = {"img255": img255, "mask": mask}
+    for tag, ch in (("c32", [32, 32, 32]), ("c8", [8, 8, 8]), ("cu", [4, 16, 6])):
+        h_unit = ref_color.histogram(torch.from_numpy(img255[0] / np.float32(255)), torch.from_numpy(mask[0]), ch)
+        h_255 = ref_color.histogram(torch.from_numpy(img255[1]), torch.from_numpy(mask[1]), ch)
+        h_raw = ref_color.histogram(torch.from_numpy(img255[1]), torch.from_numpy(mask[1]), ch, normalize=False)
+        hb = ref_color.histogram(torch.from_numpy(img255), torch.from_numpy(mask), ch)
+        out[tag + "_unit"], out[tag + "_255"], out[tag + "_raw"], out[tag + "_batched"] = h_unit.numpy(), h_255.numpy(), h_raw.numpy(), hb.numpy()
+        out[tag + "_inter"] = np.array(float(ref_color.histogram_intersection(h_unit, h_255)))
+        out[tag + "_inter_batched"] = ref_color.histogram_intersection(hb, hb.flip(0)).numpy()
+    save("g16_histogram.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

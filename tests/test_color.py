@@ -224,3 +224,23 @@ def test_histogram(cu, channels, unit_range):
     assert np.abs(hb[0].cpu().numpy() - h1.cpu().numpy()).max() <= 1e-6
     ib = cu.histogram_intersection(hb, hb.flip(0))
     assert ib.shape == (2,) and abs(float(ib[0]) - inter) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,channels", [("c32", [32, 32, 32]), ("c8", [8, 8, 8]), ("cu", [4, 16, 6])])
+def test_histogram_reference_golden(cu, tag, channels):
+    """G16: what the reference's color_utils.histogram / histogram_intersection returned (unit-range and 0..255 images,
+    normalised and raw counts, unbatched and batched forms)."""
+    g = load_golden("g16_histogram.npz")
+    img255, mask = g["img255"], g["mask"]
+    h_unit = cu.histogram(T(img255[0] / np.float32(255)), T(mask[0]), channels)
+    h_255 = cu.histogram(T(img255[1]), T(mask[1]), channels)
+    h_raw = cu.histogram(T(img255[1]), T(mask[1]), channels, normalize=False)
+    assert np.array_equal(h_raw.cpu().numpy(), g[tag + "_raw"])                       # counts: exact
+    assert np.abs(h_unit.cpu().numpy() - g[tag + "_unit"]).max() <= 1e-9            # count / total, one fp32 division
+    assert np.abs(h_255.cpu().numpy() - g[tag + "_255"]).max() <= 1e-9
+    hb = cu.histogram(T(img255), T(mask), channels)
+    assert tuple(hb.shape) == (2, *channels) and np.abs(hb.cpu().numpy() - g[tag + "_batched"]).max() <= 1e-7
+    assert abs(float(cu.histogram_intersection(h_unit, h_255)) - float(g[tag + "_inter"])) <= 1e-6
+    ib = cu.histogram_intersection(hb, hb.flip(0)).cpu().numpy()
+    assert np.abs(ib - g[tag + "_inter_batched"]).max() <= 1e-6
