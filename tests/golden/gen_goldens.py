@@ -591,10 +591,32 @@ def g16_histogram():
     save("g16_histogram.npz", **out)
 
 
+def g17_small_utils():
+    """The small helpers around the candidate grids: create_coordinate, compute_sampling_grid, adaptive_trans_num,
+    out_of_room, get_bound (utils.py:232-318, :688-755)."""
+    xyz, _ = synth.box_room(20_000, 17)
+    X = torch.from_numpy(xyz)
+    out = {"xyz": xyz}
+    out["coord_4x8"] = ref_utils.create_coordinate(4, 8).numpy()
+    yprs = np.array([[0.0, 0.0, 0.0], [0.7, -0.3, 0.2], [3.0, 1.2, -2.0]], np.float32)
+    out["yprs"] = yprs
+    out["grids_4x4"] = np.stack([ref_utils.compute_sampling_grid(torch.from_numpy(y), 4, 4).numpy() for y in yprs])
+    out["grids_2x4"] = np.stack([ref_utils.compute_sampling_grid(torch.from_numpy(y), 2, 4).numpy() for y in yprs])
+    out["adaptive_xyz_50"] = np.array(ref_utils.adaptive_trans_num(X, 50, xy_only=False))
+    out["adaptive_xy_150"] = np.array(ref_utils.adaptive_trans_num(X, 150, xy_only=True))
+    probes = np.array([[0.0, 0.0, 0.0], [3.9, 0.0, 0.0], [4.1, 0.0, 0.0], [0.0, -3.2, 0.0], [0.0, 0.0, 1.6], [-3.99, 2.99, -1.49]], np.float32)
+    out["probes"] = probes
+    out["out_of_room_q05"] = np.array([ref_utils.out_of_room(X, torch.from_numpy(p).reshape(3, 1), 0.05) for p in probes])
+    out["out_of_room_q20"] = np.array([ref_utils.out_of_room(X, torch.from_numpy(p).reshape(3, 1), 0.2) for p in probes])
+    b = ref_utils.get_bound(X, Cfg(out_of_room_quantile=0.1, max_yaw=3.0))
+    out["bound_q10"] = np.array([b[k] for k in ("x", "y", "z", "yaw", "pitch", "roll")], np.float64)
+    save("g17_small_utils.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

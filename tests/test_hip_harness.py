@@ -210,3 +210,24 @@ def test_warp_from_img_matches_golden_samples():
     # reshape_img_tensor (utils.py:632-638): uint8 round trip + bilinear resize to size = (X, Y), on the input's device
     small = utils.reshape_img_tensor(torch.full((4, 8, 3), 0.5), (4, 2))
     assert tuple(small.shape) == (2, 4, 3) and torch.allclose(small, torch.full((2, 4, 3), 127 / 255.))
+
+
+def test_small_utils_match_reference():
+    """G17: create_coordinate, compute_sampling_grid, adaptive_trans_num, out_of_room, get_bound as the reference returned
+    them for the same cloud."""
+    from piccolo_amd import utils
+    g = load_golden("g17_small_utils.npz")
+    X = torch.from_numpy(g["xyz"]).cuda()
+    assert np.abs(utils.create_coordinate(4, 8).numpy() - g["coord_4x8"]).max() <= 1e-6
+    for k, ypr in enumerate(g["yprs"]):
+        y = torch.from_numpy(ypr).cuda()
+        assert np.abs(utils.compute_sampling_grid(y, 4, 4).cpu().numpy() - g["grids_4x4"][k]).max() <= 2e-6
+        assert np.abs(utils.compute_sampling_grid(y, 2, 4).cpu().numpy() - g["grids_2x4"][k]).max() <= 2e-6
+    assert tuple(utils.adaptive_trans_num(X, 50, xy_only=False)) == tuple(g["adaptive_xyz_50"])
+    assert tuple(utils.adaptive_trans_num(X, 150, xy_only=True)) == tuple(g["adaptive_xy_150"])
+    for q, key in ((0.05, "out_of_room_q05"), (0.2, "out_of_room_q20")):
+        got = [utils.out_of_room(X, torch.from_numpy(p).reshape(3, 1), q) for p in g["probes"]]
+        assert got == [bool(v) for v in g[key]]
+    b = utils.get_bound(X, Cfg(out_of_room_quantile=0.1, max_yaw=3.0))
+    got = np.array([b[k] for k in ("x", "y", "z", "yaw", "pitch", "roll")], np.float64)
+    assert np.abs(got - g["bound_q10"]).max() <= 1e-6
