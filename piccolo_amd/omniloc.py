@@ -48,7 +48,17 @@ def _cached(kind, tensors, make):
 
 
 def packed_cloud(xyz, rgb):
-    return _cached("cloud", (xyz, rgb), lambda: ops.Cloud(xyz, rgb))
+    """Packed cloud cached per (xyz, rgb); the Morton order is cached per xyz alone, so a cloud whose colours change with
+    every query image (color_mod, localize.py:175-179) is re-packed without being re-sorted."""
+    def make():
+        first = _cache.get(("order",) + _key(xyz))
+        if first is not None and first[0][0]() is xyz:
+            return ops.Cloud(xyz, rgb, order=first[1])
+        c = ops.Cloud(xyz, rgb)
+        if c.order is not None:
+            _cache[("order",) + _key(xyz)] = ([weakref.ref(xyz)], c.order)
+        return c
+    return _cached("cloud", (xyz, rgb), make)
 
 
 def packed_pano(img, many_poses=False):

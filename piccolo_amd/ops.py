@@ -44,7 +44,9 @@ class Cloud:
 
     `order` maps packed slot -> original point index (None if the original order was kept)."""
 
-    def __init__(self, xyz, rgb, sort=True):
+    def __init__(self, xyz, rgb, sort=True, order=None):
+        """`order`: a Morton order computed before for the same xyz (Cloud(...).order): skips the sort, e.g. when only
+        the colours of a cloud changed (color_mod gives every query image its own rgb)."""
         lib = _lib.load()
         xyz, rgb = _dev(xyz), _dev(rgb)
         if xyz.dim() != 2 or xyz.shape[1] != 3 or rgb.shape != xyz.shape:
@@ -53,7 +55,11 @@ class Cloud:
         if self.n <= 0:
             raise ValueError("empty point cloud")
         self.order = None
-        if sort and self.n > 1:
+        if order is not None:
+            if order.dtype != torch.int64 or order.numel() != self.n or not order.is_cuda:
+                raise ValueError("order must be a CUDA int64 tensor with one entry per point")
+            self.order = order
+        elif sort and self.n > 1:
             self.order = torch.empty(self.n, dtype=torch.int64, device=xyz.device)
             nws = lib.pcl_cloud_order_workspace_bytes(self.n)
             ws = _bytes(nws)

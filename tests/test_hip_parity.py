@@ -636,3 +636,20 @@ def test_cloud_order_is_a_morton_sorted_permutation(ops):
     # the packed planes hold exactly the reordered points (colours negated)
     planes = cloud.data[: 6 * 4 * ops._lib.load().pcl_cloud_stride(cloud.n)].view(torch.float32).reshape(6, -1)[:, : cloud.n].cpu().numpy()
     assert np.array_equal(planes[:3].T, xyz[order]) and np.array_equal(planes[3:].T, -rgb[order])
+
+
+def test_cloud_repack_reuses_the_morton_order(ops):
+    """New colours for the same xyz (color_mod gives every query image its own rgb): the cached order is reused and the
+    packed cloud equals a from-scratch pack."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    xyz, rgb = synth.box_room(30_000, 8)
+    X, C1, C2 = T(xyz), T(rgb), T((rgb * 0.5).astype(np.float32))
+    po._cache.clear()                                            # (the pack cache holds a handful of entries and starts over)
+    a = po.packed_cloud(X, C1)
+    b = po.packed_cloud(X, C2)
+    assert b.order is a.order                                    # no second sort
+    fresh = ops.Cloud(X, C2)
+    assert torch.equal(b.order, fresh.order) and torch.equal(b.data, fresh.data)
+    with pytest.raises(ValueError):
+        ops.Cloud(X, C2, order=a.order[:-1])
