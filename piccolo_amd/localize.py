@@ -18,7 +18,7 @@ from . import data_utils
 from . import dist as pdist
 from . import ops, synth
 from .color_utils import color_match, color_mod
-from .omniloc import omniloc_all, omniloc_batch
+from .omniloc import omniloc_all, omniloc_batch, omniloc_batch_images
 from .utils import make_input, make_pano, out_of_room, resize_image, write_summaries
 
 
@@ -153,7 +153,21 @@ def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, r
         gts[k] = (gt_t, gt_r, skipped)
         return row
 
-    table = pdist.localize_sharded(len(filenames), body, dev)
+    per_launch = int(getattr(cfg, "images_per_launch", 1))
+    if per_launch > 1:
+        rank, world = pdist.world()
+        mine = pdist.shard(len(filenames), rank, world)
+        rows = torch.full((len(mine), pdist.RESULT_WIDTH), float("nan"), dtype=torch.float32)
+        batcher = _Batcher(cfg, per_launch)
+        for j, k in enumerate(mine):
+            def store(row, j=j):
+                rows[j] = row
+            _, gt_t, gt_r, skipped = per_image(k, batcher=batcher, done=store)
+            gts[k] = (gt_t, gt_r, skipped)
+        batcher.flush()
+        table = pdist.gather_rows(rows.to(dev), len(filenames), rank, world)
+    else:
+        table = pdist.localize_sharded(len(filenames), body, dev)
     rank, world = pdist.world()
     if world > 1:                                   # ground truths of the other ranks' images, for the CSV
         for k in range(len(filenames)):
@@ -208,17 +222,61 @@ def _nan_row():
     return torch.full((pdist.RESULT_WIDTH,), float("nan"))
 
 
-def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries):
-    """localize.py:199-247: make_input on the initialisation image, refinement on the main image, errors."""
+def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries, batcher=None, finish=None):
+    """localize.py:199-247: make_input on the initialisation image, refinement on the main image, errors.  With a
+    `batcher` the refinement is deferred: images of one cloud are refined together, `finish(t, R, row)` is called then."""
     init_dict = get_init_dict(cfg)
     torch.cuda.synchronize()
     t0 = time.time()
     input_trans, input_rot = make_input(img_init, xyz, rgb, getattr(cfg, "num_input", 6), init_dict,
                                         getattr(cfg, "criterion", "histogram"), getattr(cfg, "num_intermediate", 20))
+    if batcher is not None:
+        torch.cuda.synchronize()
+        batcher.submit(dict(img=img_main, xyz=xyz, rgb=rgb, trans=input_trans, rot=input_rot, gt=(gt_trans, gt_rot),
+                            init_seconds=time.time() - t0, finish=finish))
+        return None
     t, R, loss = refine_image(img_main, xyz, rgb, input_trans, input_rot, cfg, summaries)
     dt = time.time() - t0
+    return (t, R) + (_result_row(t, R, loss, gt_trans, gt_rot, dt),)
+
+
+def _result_row(t, R, loss, gt_trans, gt_rot, seconds):
     t_err, r_err = pose_errors(t, R, gt_trans, gt_rot)
-    return t, R, torch.cat([t.reshape(3), R.reshape(9), loss.reshape(1), torch.tensor([t_err, r_err, dt], dtype=torch.float32)])
+    return torch.cat([t.reshape(3), R.reshape(9), loss.reshape(1), torch.tensor([t_err, r_err, seconds], dtype=torch.float32)])
+
+
+class _Batcher:
+    """cfg.images_per_launch > 1: query images that share the cloud tensors and the image size are refined in one launch
+    chain (omniloc_batch_images) — at the shipped 6 candidates per image a launch is latency-bound, eight images cost
+    little more than one.  Images whose cloud colours were changed per image (sharpen_color) cannot share a launch and
+    go one by one."""
+
+    def __init__(self, cfg, size):
+        self.cfg, self.size, self.jobs = cfg, size, []
+
+    def submit(self, job):
+        if self.jobs and not (job["xyz"] is self.jobs[0]["xyz"] and job["rgb"] is self.jobs[0]["rgb"] and
+                              job["img"].shape == self.jobs[0]["img"].shape and job["trans"].shape == self.jobs[0]["trans"].shape):
+            self.flush()
+        self.jobs.append(job)
+        if len(self.jobs) >= self.size:
+            self.flush()
+
+    def flush(self):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        torch.cuda.synchronize()
+        t0 = time.time()
+        if len(jobs) == 1:
+            j = jobs[0]
+            results = [refine_image(j["img"], j["xyz"], j["rgb"], j["trans"], j["rot"], self.cfg)]
+        else:
+            results = omniloc_batch_images([j["img"] for j in jobs], jobs[0]["xyz"], jobs[0]["rgb"], [j["trans"] for j in jobs],
+                                           [j["rot"] for j in jobs], self.cfg, batch_mode=bool(getattr(self.cfg, "parallel", False)))
+        share = (time.time() - t0) / len(jobs)
+        for j, (t, R, loss) in zip(jobs, results):
+            j["finish"](t, R, _result_row(t, R, loss, j["gt"][0], j["gt"][1], j["init_seconds"] + share))
 
 
 def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford"):
@@ -247,7 +305,7 @@ def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford")
     cache = {}
     summaries = {}
 
-    def per_image(k, gt_only=False):
+    def per_image(k, gt_only=False, batcher=None, done=None):
         filename = filenames[k]
         area = int(filename.split("/")[-2].split("_")[-1])
         img_name = filename.split("/")[-1]
@@ -271,11 +329,19 @@ def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford")
         if getattr(cfg, "sharpen_color", False):        # localize.py:175-179: only the INITIALISATION image is equalised
             img, rgb_k = color_mod(img, rgb, int(getattr(cfg, "num_bins", 256)))
         img_main = _to_img(resize_image(orig, orig.shape[1] // mw, orig.shape[0] // mh), dev)      # localize.py:211-213
+        def report(t, R, row):
+            print("\n{}\ntranslation error : {}\nrotation error : {}\n".format(img_name, float(row[13]), float(row[14])))
+            if log_dir is not None:
+                _save_result_image(os.path.join(log_dir, "results", "area_{}".format(area), img_name), orig, xyz, rgb, t, R,
+                                   (img_main.shape[0] // 2, img_main.shape[1] // 2))
+            if done is not None:
+                done(row)
+
+        if batcher is not None:
+            _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries, batcher=batcher, finish=report)
+            return None, gt_trans, gt_rot, False
         t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries)
-        print("\n{}\ntranslation error : {}\nrotation error : {}\n".format(img_name, float(row[13]), float(row[14])))
-        if log_dir is not None:
-            _save_result_image(os.path.join(log_dir, "results", "area_{}".format(area), img_name), orig, xyz, rgb, t, R,
-                               (img_main.shape[0] // 2, img_main.shape[1] // 2))
+        report(t, R, row)
         return row, gt_trans, gt_rot, False
 
     return _run_dataset(cfg, writer, log_dir, filenames, per_image, "stanford_results.csv",
@@ -307,7 +373,7 @@ def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscen
     cache = {}
     summaries = {}
 
-    def per_image(k, gt_only=False):
+    def per_image(k, gt_only=False, batcher=None, done=None):
         filename = filenames[k]
         video = filename.split("/")[-2]
         room_type, room_no = video.split("_")[1], video.split("_")[2]
@@ -336,11 +402,19 @@ def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscen
         orig = (255 * new_img.cpu().numpy()).astype(np.uint8)
         img = _to_img(resize_image(orig, orig.shape[1] // dw, orig.shape[0] // dh), dev)
         img_main = _to_img(resize_image(orig, orig.shape[1] // mw, orig.shape[0] // mh), dev)
+        def report(t, R, row):
+            print("\n{}/{}\ntranslation error : {}\nrotation error : {}\n".format(video, filename.split("/")[-1], float(row[13]), float(row[14])))
+            if log_dir is not None:
+                _save_result_image(os.path.join(log_dir, "results", video, os.path.splitext(filename.split("/")[-1])[0] + ".png"), orig, xyz,
+                                   rgb_k, t, R, (img_main.shape[0] // 2, img_main.shape[1] // 2))
+            if done is not None:
+                done(row)
+
+        if batcher is not None:
+            _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries, batcher=batcher, finish=report)
+            return None, gt_trans, gt_rot, False
         t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries)
-        print("\n{}/{}\ntranslation error : {}\nrotation error : {}\n".format(video, filename.split("/")[-1], float(row[13]), float(row[14])))
-        if log_dir is not None:
-            _save_result_image(os.path.join(log_dir, "results", video, os.path.splitext(filename.split("/")[-1])[0] + ".png"), orig, xyz,
-                               rgb_k, t, R, (img_main.shape[0] // 2, img_main.shape[1] // 2))
+        report(t, R, row)
         return row, gt_trans, gt_rot, False
 
     return _run_dataset(cfg, writer, log_dir, filenames, per_image, "omniscenes_results.csv",

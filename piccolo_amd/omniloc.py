@@ -169,15 +169,16 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     return [out[0:3].reshape(3, 1).clone(), out[3:12].reshape(3, 3).clone(), out[12].clone()]
 
 
-def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, scalar_summaries=None):
+def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, scalar_summaries=None, batch_mode=True):
     """Throughput extension (not in the reference): omniloc_batch for SEVERAL query images of the same cloud at once.
 
     imgs: list of (H,W,3) images of one size; input_trans_list / input_rot_list: per image (B,3) starting poses (same B).
     The I * B candidates run through one chain of launches (shared cloud in L2, per-candidate panorama pointer), each with
     its own Adam / scheduler state, so every image gets the result omniloc_batch would give it (bit for bit when the
     cloud is cut into the same chunks, else up to the summation order of the partial sums); at 32 candidates per image,
-    8 images per launch are ~25 % faster than 8 separate refinements.  Returns a list of [t, R, loss]."""
-    if strict_reference_asserts:
+    8 images per launch are ~25 % faster than 8 separate refinements.  Returns a list of [t, R, loss].
+    batch_mode=False gives every candidate omniloc's SEQUENTIAL semantics instead (what omniloc_all computes per image)."""
+    if strict_reference_asserts and batch_mode:
         assert cfg.num_input > 1
     I = len(imgs)
     B = int(input_trans_list[0].shape[0])
@@ -190,7 +191,7 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
     tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])
     ro = torch.cat([ops._dev(r).reshape(B, 3) for r in input_rot_list])
     gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
-                             factor=_cfg(cfg, "factor", 0.9), batch_mode=True, depth_mask=_cfg(cfg, "depth_mask", False),
+                             factor=_cfg(cfg, "factor", 0.9), batch_mode=batch_mode, depth_mask=_cfg(cfg, "depth_mask", False),
                              depth_tau=_cfg(cfg, "depth_tau", 0.02))
     gd.set_panos([panos[i] for i in range(I) for _ in range(B)])
     gd.run(_cfg(cfg, "num_iter", 100))

@@ -92,6 +92,10 @@ def test_localize_stanford_layout(tmp_path):
     assert np.abs(est - POSES[0][0]).max() < 0.15
     img = Image.open(log / "results/area_3" / names[0])
     assert img.size == (W // 2, 2 * (H // 2))                               # GT panorama over the render, half resolution
+    # images_per_launch with sharpen_color: every image has its own equalised cloud colours, so the batcher falls back to
+    # one image per launch — same table as above
+    again = localize.localize_stanford(Cfg(**{**cfg.__dict__, "images_per_launch": 4}), None, None, root=str(root)).cpu().numpy()
+    assert np.array_equal(np.isnan(again), np.isnan(table)) and np.allclose(again[:2, :13], table[:2, :13], atol=0, rtol=0)
 
 
 def test_localize_omniscenes_layout(tmp_path):
@@ -132,6 +136,13 @@ def test_localize_omniscenes_layout(tmp_path):
     assert table.shape == (2, 16) and np.isfinite(table).all()
     with open(tmp_path / "log2" / "omniscenes_results.csv") as f:
         assert len(list(csv.reader(f))) == 3
+    # images_per_launch: both frames of the room refined in one launch chain (same cloud tensors, same image size); every
+    # frame still gets its own row; frame 1 again localised
+    both = localize.localize_omniscenes(Cfg(images_per_launch=4, **base), None, str(tmp_path / "log3"), root=str(root)).cpu().numpy()
+    assert both.shape == (2, 16) and np.isfinite(both).all() and both[1, 13] < 0.08 and both[1, 14] < 1.5
+    with open(tmp_path / "log3" / "omniscenes_results.csv") as f:
+        assert len(list(csv.reader(f))) == 3
+    assert (tmp_path / "log3" / "results" / video / "000001.png").exists()
     # filters of the loop
     none = localize.localize_omniscenes(Cfg(**{**base, "scene_number": 7}), None, None, root=str(root))
     assert tuple(none.shape) == (0, 16)
