@@ -244,15 +244,20 @@ def generate_trans_points(xyz, init_dict=None, device="cpu"):
     return torch.stack([c.reshape(-1) for c in g], dim=1)
 
 
+_ROT_GRIDS = {}
+
+
 def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", num_intermediate=None):
     """Starting poses for the refinement (utils.py:591-629): candidate grid -> sampling-loss trim -> histogram trim.
     Only criterion == 'loss_histogram' exists in the reference (anything else hits an unbound local there)."""
     # the candidate grids depend on the cloud and the config only, not on the query image: build them once per cloud
     # (the reference rebuilds them for every image; ~10 ms of small tensor ops, torch.quantile's NaN scans included)
     from .omniloc import _cached
-    key = "grid:" + repr(sorted((k, str(v)) for k, v in init_dict.items())) + str(img.device)
-    rot, trans = _cached(key, (xyz,), lambda: (generate_rot_points(init_dict, device=img.device),
-                                               generate_trans_points(xyz, init_dict, device=img.device)))
+    key = repr(sorted((k, str(v)) for k, v in init_dict.items())) + str(img.device)
+    rot = _ROT_GRIDS.get(key)                       # the rotation grid depends on the config alone: once per process
+    if rot is None:
+        rot = _ROT_GRIDS[key] = generate_rot_points(init_dict, device=img.device)
+    trans = _cached("grid:" + key, (xyz,), lambda: generate_trans_points(xyz, init_dict, device=img.device))
     if init_dict["sample_rate_for_init"] is not None:
         raise NotImplementedError("sample_rate_for_init: broken in the reference too (utils.py:618-620)")
     if criterion != "loss_histogram":
