@@ -97,7 +97,8 @@ def quantile(x, q):
 
 def out_of_room(xyz, trans, out_quantile=0.05):
     """True if `trans` (3,1) is outside the open [q, 1-q] quantile box of the cloud."""
-    box = ops.quantile_box(xyz, out_quantile).cpu()
+    from .omniloc import _cached                     # the box is loop invariant: shared with omniloc / omniloc_batch
+    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile)).cpu()
     t = torch.as_tensor(trans).detach().cpu().reshape(3)
     inside = all(box[2 * k] < t[k] < box[2 * k + 1] for k in range(3))
     return not inside
