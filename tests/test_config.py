@@ -58,12 +58,12 @@ def test_override_grammar(tmp_path):
 
 
 def test_dropin_modules_resolve_to_the_mi355x_implementation():
-    """What the reference's localize.py imports (localize.py:13,15) must exist under the drop-in names."""
+    """What the reference's localize.py imports (localize.py:11-15) must exist under the drop-in names."""
     import importlib
     import sys
     sys.path.insert(0, os.path.join(REPO, "dropin"))
     try:
-        for name in ("omniloc", "utils", "parse_utils"):
+        for name in ("omniloc", "utils", "parse_utils", "color_utils", "data_utils"):
             sys.modules.pop(name, None)
         om = importlib.import_module("omniloc")
         ut = importlib.import_module("utils")
@@ -73,7 +73,12 @@ def test_dropin_modules_resolve_to_the_mi355x_implementation():
                    "rot_from_ypr", "trim_input_loss", "generate_rot_points", "generate_trans_points"):
             assert callable(getattr(ut, fn)), fn
         assert pu.parse_ini and pu.parse_value and pu.save_ini
+        cu = importlib.import_module("color_utils")                   # `from color_utils import color_mod, color_match`
+        du = importlib.import_module("data_utils")                    # `import data_utils`
+        assert cu.color_mod.__module__ == "piccolo_amd.color_utils" and cu.color_match and cu.histogram and cu.histogram_intersection
+        for fn in ("read_stanford", "read_omniscenes", "obtain_gt_stanford", "obtain_gt_omniscenes"):
+            assert getattr(du, fn).__module__ == "piccolo_amd.data_utils", fn
     finally:
         sys.path.remove(os.path.join(REPO, "dropin"))
-        for name in ("omniloc", "utils", "parse_utils"):
+        for name in ("omniloc", "utils", "parse_utils", "color_utils", "data_utils"):
             sys.modules.pop(name, None)
