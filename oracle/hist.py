@@ -6,8 +6,11 @@ rows (h = 1 .. num_split_h - 2, utils.py:556) intersect the normalised 8x8x8 col
 (where both the render and the query image are non-black) with the histogram of the query image's non-black pixels;
 score = sum of the block intersections / (num_split_h * num_split_w).  Candidates are ranked by score, best first.
 
-Quirk not reproduced: when a block is empty the reference `break`s out of the block row and keeps whatever the previous
-candidate left in the remaining slots (utils.py:568-571); here those slots count as 0.
+Quirk reproduced (pinned by G19): the reference keeps ONE slot vector `hist_intersect_split` for all candidates
+(utils.py:539).  A block with no rendered or no query pixel writes 0 into its slot and `break`s out of its block row
+(utils.py:568-571); the remaining slots of that row keep whatever the last candidate that reached them left there, so a
+candidate's score can include an earlier candidate's intersections.  `inter` returned here is that slot vector as it
+stands after each candidate (NaNs cleaned in place, utils.py:579).
 """
 import math
 
@@ -41,6 +44,7 @@ def hist_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w):
     img_code = _codes(img255)
     K = len(trans)
     inter = np.zeros((K, num_split_h * num_split_w), np.float64)
+    slots = np.zeros(num_split_h * num_split_w, np.float64)          # hist_intersect_split: allocated once (utils.py:539)
     for i in range(K):
         R = orc.rot_from_ypr(rot[i], np.float32)
         cam = ((np.asarray(xyz, np.float32) - np.asarray(trans[i], np.float32)[None, :]) @ R.T).astype(np.float32)
@@ -52,8 +56,11 @@ def hist_scores(img, xyz, rgb, trans, rot, num_split_h, num_split_w):
                 hp, n_p = block_hist(proj_code, both, h, w, bh, bw)
                 hq, n_q = block_hist(img_code, img_mask, h, w, bh, bw)
                 if n_p == 0 or n_q == 0:
+                    slots[h * num_split_w + w] = 0.0                 # utils.py:569-571: zero this slot, leave the row
                     break
-                inter[i, h * num_split_w + w] = float(np.minimum(hp, hq).sum())
+                slots[h * num_split_w + w] = float(np.minimum(hp, hq).sum())
+        slots[np.isnan(slots)] = 0.0                                 # utils.py:579, in place
+        inter[i] = slots
     scores = inter.sum(1) / (num_split_h * num_split_w)
     return scores, inter
 

@@ -7,10 +7,10 @@
 // Off by default: with the mask off the loss is exactly the reference's.
 //
 // Two passes over the cloud per call, both projection + one 4-byte access per point-pose:
-//   z pass   : 32-bit atomicMin of the squared depth's bit pattern (>= 0, so it orders like the float).  Points are in
-//              Morton order, so a wave's atomics fall into a small pixel patch: they resolve in L2 (95 % hit), and most
-//              pixels receive 0-2 points at 1 point per 2 pixels, so there is little same-address serialisation
-//              to remove with LDS tiling.
+//   z pass   : 32-bit atomicMin of the squared depth's bit pattern (>= 0, so it orders like the float).  Done as one
+//              global atomic per point-pose it is the slow shape of the chip — 616 us at cfg 2, six times the mark pass
+//              that does the same projection without atomics — so it is LDS-tiled (below): a block resolves its
+//              Morton-compact pixel patch with LDS atomics and flushes it row by row, 276 us.
 //   mark pass: re-project, compare with the z-buffer, write one byte per point-pose.
 #include <stdlib.h>
 

@@ -214,10 +214,18 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         // time every `stride`-th launch only: an event pair costs a few microseconds of GPU timeline, which would
         // distort short kernels if it bracketed all of them
         const bool timed = tm && tm->used < tm->capacity && (it % tm->stride) == 0;
-        if (timed) (void)hipEventRecord(tm->start[tm->used], s);
+        if (timed) {
+            hipError_t e = hipEventRecord(tm->start[tm->used], s);
+            if (e != hipSuccess) return (int)e;
+        }
         int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s);
-        if (timed) (void)hipEventRecord(tm->stop[tm->used++], s);
         if (rc) return rc;
+        if (timed) {
+            // (only a completed start/stop pair counts as used: pcl_timer_read never sees a half-recorded slot)
+            hipError_t e = hipEventRecord(tm->stop[tm->used], s);
+            if (e != hipSuccess) return (int)e;
+            tm->used++;
+        }
         hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, nchunks, B, gd_poses(state),
                            gd_recs(state, B), box, hyper_host->factor, (int)hyper_host->patience, (int)hyper_host->mode,
                            loss_history ? loss_history + (int64_t)it * B : nullptr);

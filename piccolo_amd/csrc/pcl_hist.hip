@@ -241,32 +241,53 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     return 0;
 }
 
-// score[cand] = sum over the block rows of the intersections up to (not including) the first empty block of the row,
-// divided by nsh * nsw: the reference `break`s out of a block row at the first block where the render or the query has no
-// pixel to histogram (utils.py:568-571) and divides by all nsh * nsw blocks (utils.py:580).  One thread per candidate.
-__global__ void pcl_hist_score_kernel(const float* __restrict__ inter, const int* __restrict__ nproj, const int* __restrict__ nimg,
-                                      int ncand, int nsh, int nsw, float* __restrict__ score)
+// Scores with the reference's slot semantics.  The reference keeps ONE vector `hist_intersect_split` of nsh * nsw slots for
+// all candidates (allocated before the candidate loop, utils.py:539): a block with nothing to histogram — no rendered or no
+// query pixel — writes 0 into its slot and `break`s out of its block ROW (utils.py:568-571); the row's remaining slots
+// are not touched, so they still hold what the last candidate that got that far left there (possibly itself a stale
+// value), NaNs cleaned to 0 in place (utils.py:579).  score = sum of the slots / (nsh * nsw) (utils.py:580).  Pinned by
+// G19 (per-candidate slot vectors read out of the running reference function).
+// The carry makes the candidates a sequential chain per slot: one block, thread j owns slot j (strided if there are more
+// slots than threads) and walks the candidates in order, its carried value in LDS; thread 0 sums each candidate's slots in
+// slot order (deterministic).  K is a few dozen candidates, nblk a few dozen slots: microseconds.
+__global__ void __launch_bounds__(256) pcl_hist_score_kernel(const float* __restrict__ inter, const int* __restrict__ nproj,
+                                                             const int* __restrict__ nimg, int ncand, int nsh, int nsw,
+                                                             float* __restrict__ score)
 {
-    int cand = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cand >= ncand) return;
+    extern __shared__ float slot[];                       // [nblk] current content of hist_intersect_split (middle rows)
     const int nblk = (nsh - 2) * nsw;
-    float total = 0.f;
-    for (int h = 0; h < nsh - 2; h++)
-        for (int w = 0; w < nsw; w++) {
-            int j = h * nsw + w;
-            if (nproj[(int64_t)cand * nblk + j] == 0 || nimg[j] == 0) break;
-            float v = inter[(int64_t)cand * nblk + j];
-            total += (v == v) ? v : 0.f;
+    for (int j = threadIdx.x; j < nblk; j += blockDim.x) slot[j] = 0.f;
+    __syncthreads();
+    for (int cand = 0; cand < ncand; cand++) {
+        const int* np = nproj + (int64_t)cand * nblk;
+        for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
+            const int row0 = (j / nsw) * nsw;
+            int first_empty = nsw;                        // position in the row where the reference breaks
+            for (int w = 0; w < nsw; w++)
+                if (np[row0 + w] == 0 || nimg[row0 + w] == 0) { first_empty = w; break; }
+            const int w = j - row0;
+            if (w < first_empty) {
+                float v = inter[(int64_t)cand * nblk + j];
+                slot[j] = (v == v) ? v : 0.f;
+            } else if (w == first_empty) slot[j] = 0.f;   // (w > first_empty: untouched, keeps the earlier candidate's value)
         }
-    score[cand] = total / (float)(nsh * nsw);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float total = 0.f;
+            for (int j = 0; j < nblk; j++) total += slot[j];
+            score[cand] = total / (float)(nsh * nsw);
+        }
+        __syncthreads();
+    }
 }
 
 extern "C" int pcl_hist_trim_reduce(const float* inter, const int32_t* nproj, const int32_t* nimg, int ncand, int nsh, int nsw, float* score,
                                     void* stream)
 {
     if (!inter || !nproj || !nimg || !score || ncand <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
-    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3((ncand + 255) / 256), dim3(256), 0, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw,
-                       score);
+    const size_t lds = (size_t)(nsh - 2) * nsw * sizeof(float);
+    if (lds > 60000) return PCL_EINVAL;                   // > 15000 blocks: not a block grid this stage is meant for
+    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw, score);
     PCL_LAUNCH_CHECK();
     return 0;
 }

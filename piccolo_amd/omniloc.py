@@ -18,6 +18,7 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     an empty frame list as 4th element instead of raising NameError.
 """
 import weakref
+from collections import OrderedDict
 
 import torch
 import torch.nn as nn
@@ -28,35 +29,80 @@ strict_reference_asserts = True
 
 # ------------------------------------------------------------------------------------------------ pack caches
 # The harness calls omniloc() once per starting point with the same img/xyz/rgb (localize.py:219-220): pack once.
-_cache = {}
+# One small LRU per KIND of packed object, so a stream of query images can never evict the room's Morton order, packed
+# cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
+# An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
+# references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
+_CAPACITY = {"cloud": 2, "order": 2, "box": 4, "grid": 4, "pano": 16, "pano_u8": 4}
+
+
+class _PackCache:
+    def __init__(self):
+        self.kinds = {}                     # kind -> OrderedDict(key -> ([weakrefs], object)), least recent first
+
+    def _lru(self, kind):
+        lru = self.kinds.get(kind)
+        if lru is None:
+            lru = self.kinds[kind] = OrderedDict()
+        return lru
+
+    def get(self, kind, key, tensors):
+        lru = self._lru(kind)
+        hit = lru.get(key)
+        if hit is not None and all(r() is t for r, t in zip(hit[0], tensors)):
+            lru.move_to_end(key)
+            return hit[1]
+        return None
+
+    def put(self, kind, key, tensors, obj):
+        lru = self._lru(kind)
+        for k in [k for k, (refs, _) in lru.items() if any(r() is None for r in refs)]:
+            del lru[k]                      # the tensors are gone: the address may be reused by another tensor
+        lru[key] = ([weakref.ref(t) for t in tensors], obj)
+        lru.move_to_end(key)
+        while len(lru) > _CAPACITY.get(kind, 4):
+            lru.popitem(last=False)
+
+    def clear(self):
+        self.kinds.clear()
+
+    def __len__(self):
+        return sum(len(v) for v in self.kinds.values())
+
+
+_cache = _PackCache()
 
 
 def _key(*tensors):
     return tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype) for t in tensors)
 
 
-def _cached(kind, tensors, make):
-    k = (kind,) + _key(*tensors)
-    hit = _cache.get(k)
-    if hit is not None and all(r() is t for r, t in zip(hit[0], tensors)):
-        return hit[1]
-    obj = make()
-    if len(_cache) > 8:
-        _cache.clear()
-    _cache[k] = ([weakref.ref(t) for t in tensors], obj)
+def _cached(kind, tensors, make, sub=None):
+    """`kind` selects the LRU (and its capacity), `sub` distinguishes entries of one kind made from the same tensors
+    (the quantile of a box, the config of a candidate grid)."""
+    k = (sub,) + _key(*tensors)
+    obj = _cache.get(kind, k, tensors)
+    if obj is None:
+        obj = make()
+        _cache.put(kind, k, tensors, obj)
     return obj
+
+
+def quantile_box_of(xyz, out_quantile):
+    """The clamp box of omniloc.py:53-55 / :245-247, computed once per (cloud, quantile)."""
+    return _cached("box", (xyz,), lambda: ops.quantile_box(xyz, out_quantile), sub=float(out_quantile))
 
 
 def packed_cloud(xyz, rgb):
     """Packed cloud cached per (xyz, rgb); the Morton order is cached per xyz alone, so a cloud whose colours change with
     every query image (color_mod, localize.py:175-179) is re-packed without being re-sorted."""
     def make():
-        first = _cache.get(("order",) + _key(xyz))
-        if first is not None and first[0][0]() is xyz:
-            return ops.Cloud(xyz, rgb, order=first[1])
+        order = _cache.get("order", (None,) + _key(xyz), (xyz,))
+        if order is not None:
+            return ops.Cloud(xyz, rgb, order=order)
         c = ops.Cloud(xyz, rgb)
         if c.order is not None:
-            _cache[("order",) + _key(xyz)] = ([weakref.ref(xyz)], c.order)
+            _cache.put("order", (None,) + _key(xyz), (xyz,), c.order)
         return c
     return _cached("cloud", (xyz, rgb), make)
 
@@ -102,7 +148,7 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
 
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
     # the reference recomputes these three quantiles every iteration (omniloc.py:53-55); they are loop invariant
-    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    box = quantile_box_of(xyz, out_quantile)
     gd = ops.GradientDescent(cloud, pano, input_trans[starting_point], input_rot[starting_point], box,
                              lr=lr, patience=patience, factor=factor, batch_mode=False,
                              depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
@@ -126,7 +172,7 @@ def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=Non
     the next forward reads) and the points never interact, so the list returned equals the K separate calls."""
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
-    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    box = quantile_box_of(xyz, out_quantile)
     gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
                              factor=_cfg(cfg, "factor", 0.9), batch_mode=False, depth_mask=_cfg(cfg, "depth_mask", False),
                              depth_tau=_cfg(cfg, "depth_tau", 0.02))
@@ -154,7 +200,7 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
 
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
-    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    box = quantile_box_of(xyz, out_quantile)
     gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=lr, patience=patience, factor=factor,
                              batch_mode=True, depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
     gd.run(num_iter)
@@ -187,7 +233,7 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
     if len({p.fmt for p in panos}) > 1:          # a launch needs ONE texel format: float4 holds any image
         panos = [ops.Pano(im, fmt="f32") for im in imgs]
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
-    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile))
+    box = quantile_box_of(xyz, out_quantile)
     tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])
     ro = torch.cat([ops._dev(r).reshape(B, 3) for r in input_rot_list])
     gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),

@@ -97,8 +97,8 @@ def quantile(x, q):
 
 def out_of_room(xyz, trans, out_quantile=0.05):
     """True if `trans` (3,1) is outside the open [q, 1-q] quantile box of the cloud."""
-    from .omniloc import _cached                     # the box is loop invariant: shared with omniloc / omniloc_batch
-    box = _cached("box%g" % out_quantile, (xyz,), lambda: ops.quantile_box(xyz, out_quantile)).cpu()
+    from .omniloc import quantile_box_of             # the box is loop invariant: shared with omniloc / omniloc_batch
+    box = quantile_box_of(xyz, out_quantile).cpu()
     t = torch.as_tensor(trans).detach().cpu().reshape(3)
     inside = all(box[2 * k] < t[k] < box[2 * k + 1] for k in range(3))
     return not inside
@@ -258,7 +258,7 @@ def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", 
     rot = _ROT_GRIDS.get(key)                       # the rotation grid depends on the config alone: once per process
     if rot is None:
         rot = _ROT_GRIDS[key] = generate_rot_points(init_dict, device=img.device)
-    trans = _cached("grid:" + key, (xyz,), lambda: generate_trans_points(xyz, init_dict, device=img.device))
+    trans = _cached("grid", (xyz,), lambda: generate_trans_points(xyz, init_dict, device=img.device), sub=key)
     if init_dict["sample_rate_for_init"] is not None:
         raise NotImplementedError("sample_rate_for_init: broken in the reference too (utils.py:618-620)")
     if criterion != "loss_histogram":

@@ -613,10 +613,101 @@ def g17_small_utils():
     save("g17_small_utils.npz", **out)
 
 
+# ----------------------------------------------------------------------------- G18
+def g18_end_to_end_many_seeds():
+    """The reference's full 100-iteration refinements over 32 scenes, each run twice (original and permuted point order:
+    the second run is the reference's own fp32 self-noise) — sequential omniloc from one start, and for 8 scenes also
+    omniloc_batch with 4 starts.  The query panoramas come from the deterministic C oracle renderer (oracle.make_pano_u8;
+    the reference's own make_pano is set-valued, see G8), so the test regenerates them from the seed; a checksum is kept."""
+    from oracle import oracle as orc
+    N, H, W, S = 20000, 128, 256, 32
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, visualize=False, num_input=4)
+    rows, rows_b, sums = [], [], []
+    for s in range(S):
+        seed = 300 + s
+        xyz, rgb = synth.box_room(N, seed=seed)
+        t_gt, ypr_gt = synth.gt_pose(seed)
+        img_u8 = orc.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W))
+        sums.append(int(img_u8.astype(np.int64).sum()))
+        img = img_u8.astype(np.float32) / 255.0
+        trans, rot = synth.start_poses(t_gt, ypr_gt, 4, seed=seed)
+        R_gt = synth.rot_from_ypr_np(ypr_gt)
+        perm = np.random.default_rng(1000 + s).permutation(N)
+        out = []
+        for x, c in ((xyz, rgb), (xyz[perm], rgb[perm])):
+            r = ref_omniloc.omniloc(torch.from_numpy(img), torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(trans.copy()),
+                                    torch.from_numpy(rot.copy()), 0, cfg, {})
+            t, R = r[0].detach().numpy().reshape(3), r[1].detach().numpy()
+            out.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+        rows.append(np.stack(out))
+        if s < 8:
+            out = []
+            for x, c in ((xyz, rgb), (xyz[perm], rgb[perm])):
+                r = ref_omniloc.omniloc_batch(torch.from_numpy(img), torch.from_numpy(x), torch.from_numpy(c),
+                                              torch.from_numpy(trans.copy()), torch.from_numpy(rot.copy()), cfg, {})
+                t, R = r[0].detach().numpy().reshape(3), r[1].detach().numpy()
+                out.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+            rows_b.append(np.stack(out))
+        print("G18 seed %d seq t_err %.4f / %.4f (perm)  r_err %.3f / %.3f" % (seed, rows[-1][0, 13], rows[-1][1, 13], rows[-1][0, 14], rows[-1][1, 14]), flush=True)
+    # columns: t(3) R(9) loss t_err r_err ; axis 1: original / permuted point order
+    save("g18_end_to_end_seeds.npz", N=N, H=H, W=W, seed0=300, seq=np.stack(rows), batch=np.stack(rows_b), img_sum=np.array(sums))
+
+
+# ----------------------------------------------------------------------------- G19
+def g19_trim_hist_empty_blocks():
+    """trim_input_hist_secondary (utils.py:510-588) on a PARTIAL cloud (floor + one wall panel), so that for most
+    candidates some blocks of the middle block rows are empty.  The reference then `break`s out of the block row
+    (utils.py:568-571) and the remaining slots of `hist_intersect_split` — allocated once, outside the candidate loop
+    (utils.py:539) — keep what EARLIER candidates left there: a candidate's score includes stale intersections.
+    Captured from the function itself: the per-candidate `hist_intersect_split` (read from the function's frame each time
+    its progress bar is updated, i.e. after the NaN clean-up at utils.py:579) and the full ranking (num_input = K)."""
+    full_xyz, full_rgb = synth.box_room(30000, seed=19)
+    keep = (full_xyz[:, 2] < -1.49) | ((full_xyz[:, 0] > 3.99) & (np.abs(full_xyz[:, 1]) < 1.5))
+    xyz, rgb = full_xyz[keep], full_rgb[keep]
+    t_gt, ypr_gt = synth.gt_pose(19)
+    H, W, nh, nw = 64, 128, 4, 4
+    # the query image shows the WHOLE room (no empty block on its side); the candidates render the partial cloud
+    img = ref_utils.make_pano(torch.from_numpy(synth.transform_cloud(full_xyz, t_gt, ypr_gt)), torch.from_numpy(full_rgb),
+                              resolution=(H, W)).astype(np.float32) / 255.0
+    rng = np.random.default_rng(19)
+    K = 12
+    trans = (t_gt[None] + rng.normal(0, 0.4, size=(K, 3))).astype(np.float32)
+    rot = np.stack([ypr_gt[0] + np.arange(K) * (2 * np.pi / K) * 1.7, ypr_gt[1] + rng.normal(0, 0.1, K), ypr_gt[2] + rng.normal(0, 0.1, K)], 1).astype(np.float32)
+    trans[3], rot[3] = t_gt, ypr_gt
+    captured = []
+
+    class Bar:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def update(self, n):
+            captured.append(sys._getframe(1).f_locals["hist_intersect_split"].clone().numpy())
+
+    real = ref_utils.tqdm
+    ref_utils.tqdm = Bar
+    try:
+        sel_t, sel_r = ref_utils.trim_input_hist_secondary(torch.from_numpy(img), torch.from_numpy(xyz), torch.from_numpy(rgb),
+                                                           torch.from_numpy(trans), torch.from_numpy(rot), K, nh, nw)
+    finally:
+        ref_utils.tqdm = real
+    split = np.stack(captured)                                  # (K, nh*nw) effective slots per candidate
+    scores = split.sum(1) / (nh * nw)
+    print("G19 split rows:\n", np.round(split[:, nw:3 * nw], 3), "\nscores", np.round(scores, 4))
+    save("g19_trim_hist_empty_blocks.npz", xyz=xyz, rgb=rgb, img=img, trans=trans, rot=rot, split=split, scores=scores,
+         ranked_trans=sel_t.numpy(), ranked_rot=sel_r.numpy(), num_split=np.array([nh, nw]))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
-            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils]
+            g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils,
+            g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

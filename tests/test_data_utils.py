@@ -1,6 +1,7 @@
 """Dataset text clouds and ground-truth pose conventions: the native host parser and the pose helpers
 against what the reference's data_utils.py returned for the same files (tests/golden/g15_data_utils.npz; the fixture
-holds the text / pose inputs and the reference's outputs).  Host code only: runs without a GPU."""
+holds the text / pose inputs and the reference's outputs).  The parser and the pose helpers are host code and are tested
+without a GPU; the `gpu`-marked tests at the end take the parsed file all the way into the loss kernel."""
 import json
 import os
 
@@ -124,3 +125,54 @@ def test_gt_poses(du, tmp_path):
     np.savetxt(tmp_path / "omni" / "pose" / "room_1.txt", g["omni"])
     to, ro = du.obtain_gt_omniscenes(str(tmp_path / "omni" / "pano" / "room_1.jpg"))
     assert np.array_equal(to, g["omni_t"]) and np.array_equal(ro, g["omni_r"])
+
+
+# ------------------------------------------------------------------------------------------------ file -> GPU (-m gpu)
+@pytest.mark.gpu
+def test_load_cloud_gives_the_reference_tensors_on_the_gpu(du, cloud_file):
+    """load_cloud: dataset text file -> float32 CUDA tensors.  The reference gets there by read_stanford (pandas, float64,
+    rgb / 255. in float64) and torch.from_numpy(...).float().to(device) (localize.py:159-162): the tensors must hold exactly
+    the float32 roundings of G15's doubles — with and without the binary side-car cache, and with subsampling."""
+    import torch
+    g = load_golden("g15_data_utils.npz")
+    side = cloud_file + ".pcl.npy"
+    if os.path.exists(side):
+        os.remove(side)
+    for attempt in ("parse", "side-car"):
+        xyz, rgb = du.load_cloud(cloud_file)
+        assert xyz.is_cuda and rgb.is_cuda and xyz.dtype == torch.float32 and rgb.dtype == torch.float32
+        assert np.array_equal(xyz.cpu().numpy(), g["xyz"].astype(np.float32)), attempt
+        assert np.array_equal(rgb.cpu().numpy(), g["rgb"].astype(np.float32)), attempt
+        assert os.path.exists(side)
+    np.random.seed(7)
+    xs, cs = du.load_cloud(cloud_file, sample_rate=4)
+    assert np.array_equal(xs.cpu().numpy(), g["xyz_s4"].astype(np.float32)) and np.array_equal(cs.cpu().numpy(), g["rgb_s4"].astype(np.float32))
+    xyz2, _ = du.load_cloud(cloud_file, cache=False)
+    assert torch.equal(xyz2, xyz)
+
+
+@pytest.mark.gpu
+def test_text_cloud_through_the_loss_kernel(du, oracle, parity, tmp_path):
+    """A dataset-format text cloud written to disk, parsed by the native reader, uploaded, packed and evaluated by the HIP
+    loss kernel == the fp64 oracle fed the doubles numpy parses from the same text (rounded to float32 like the
+    reference's .float())."""
+    import torch
+    from parity_helpers import T, _check_vs_oracle, _oracle_pair
+    from piccolo_amd import ops, synth
+    n, H, W, B = 30_011, 96, 192, 4
+    xyz, rgb = synth.box_room(n, 77)
+    lv = np.rint(rgb * 255).astype(np.int64)                       # dataset colours are 8-bit levels
+    path = tmp_path / "room.txt"
+    with open(path, "w") as f:
+        for p, c in zip(xyz.astype(np.float64), lv):
+            f.write("%.6f %.6f %.6f %d %d %d\n" % (p[0], p[1], p[2], c[0], c[1], c[2]))
+    X, C = du.load_cloud(str(path))
+    table = np.loadtxt(path)                                        # an independent parser
+    x32, c32 = table[:, :3].astype(np.float32), (table[:, 3:] / 255.).astype(np.float32)
+    assert np.array_equal(X.cpu().numpy(), x32) and np.array_equal(C.cpu().numpy(), c32)
+    t_gt, ypr_gt = synth.gt_pose(77)
+    img = oracle.make_pano_u8(synth.transform_cloud(x32, t_gt, ypr_gt), c32, (H, W)).astype(np.float32) / 255
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=77)
+    out = ops.sampling_loss(ops.Cloud(X, C), ops.Pano(T(img)), T(trans), T(rot)).cpu().numpy()
+    r64, r32 = _oracle_pair(oracle, x32, c32, img, trans, rot)
+    _check_vs_oracle(parity, out, r64, r32, n)

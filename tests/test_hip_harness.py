@@ -160,6 +160,31 @@ def test_hist_trim_scores_vs_oracle_and_reference_golden(oracle):
     assert (z == 0).all()
 
 
+def test_hist_trim_empty_blocks_carry_over_like_the_reference(oracle):
+    """G19: candidates whose render leaves a block empty.  The reference's score then includes what earlier candidates left
+    in the rest of that block row (utils.py:539,568-571); the fixture holds the reference's per-candidate slot vectors.
+    Scores and ranking must follow the reference, also when the candidates are rendered in several batches."""
+    from oracle import hist
+    from piccolo_amd import ops, utils
+    g = load_golden("g19_trim_hist_empty_blocks.npz")
+    nh, nw = [int(v) for v in g["num_split"]]
+    dev = torch.device("cuda")
+    I, X, C = [torch.from_numpy(g[k]).to(dev) for k in ("img", "xyz", "rgb")]
+    tr, ro = torch.from_numpy(g["trans"]).to(dev), torch.from_numpy(g["rot"]).to(dev)
+    cloud = ops.Cloud(X, C)
+    ref, _ = hist.hist_scores(g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], nh, nw)
+    for batch in (16, 5):
+        scores = ops.hist_trim_scores(I, cloud, tr, ro, nh, nw, batch=batch).cpu().numpy()
+        assert np.abs(scores - ref).max() <= 2e-3, (batch, np.abs(scores - ref).max())
+        assert np.abs(scores - g["scores"]).max() <= 1e-2
+    # without the carry-over the scores would be visibly different: the quirk is really exercised
+    no_carry = g["split"].copy()
+    no_carry[6, nw + 1:nw + 3] = 0
+    assert abs(no_carry[6].sum() / (nh * nw) - g["scores"][6]) > 1e-2
+    tt, trr = utils.trim_input_hist_secondary(I, X, C, tr, ro, 4, nh, nw)
+    assert np.array_equal(tt.cpu().numpy(), g["ranked_trans"][:4]) and np.array_equal(trr.cpu().numpy(), g["ranked_rot"][:4])
+
+
 def test_omniloc_all_equals_sequential_calls():
     """omniloc_all = the reference's `for i: omniloc(..., i, ...)` loop in one launch chain, result by result."""
     from piccolo_amd import omniloc as po
@@ -177,27 +202,68 @@ def test_omniloc_all_equals_sequential_calls():
     assert torch.equal(t_all, t_seq) and torch.equal(r_all, r_seq)      # the callers' rows end up identical too
 
 
+def _run_bench(cmd, env_extra, timeout=900):
+    import json as js
+    import os
+    import subprocess
+    from conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]             # rank 0 prints exactly one JSON line ...
+    assert out.stdout.rstrip().endswith(lines[0])          # ... and it is the last thing on stdout (RCCL banner flushed before)
+    return js.loads(lines[0])
+
+
 def test_bench_two_ranks_end_to_end(tmp_path):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), here
     with two ranks sharing the one GPU over gloo: exercises the sharding of query images, the barrier-bracketed timing,
     the max-over-ranks reduction and the result gather on real kernels."""
-    import json as js
+    import os
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "cfg1", "--no-cpu-baseline", "--min-seconds", "0.2"]
+    d = _run_bench(cmd, {"PCL_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "candidate-poses/s"
+    assert d["ranks_seen"] == 2                              # the gathered rows carry both ranks' stamps
+    assert d["value"] > 0 and abs(d["value"] - 1 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert d["passes"] >= 1 and d["pass_ms"]["min"] <= d["pass_ms"]["median"] <= d["pass_ms"]["max"]
+    assert d["median_t_err_m"] < 0.1 and "roofline" in d and d["vs_baseline"] is None
+    s = d["single_image"]                                    # cfg 1: 2 images per launch chain by default, 1 in this pass
+    assert s["images_per_launch"] == 1 and s["value"] > 0 and s["poses_per_launch"] == 1
+
+
+def test_bench_rccl_path_at_world_size_one():
+    """N > 1 readiness on a one-GPU box: PCL_BENCH_FORCE_DIST=1 takes bench.py through everything an N-GPU run does —
+    RCCL init bound to the device, the warm-up all_gather, barriers, all_reduce(MAX) of the time, the result
+    all_gather_into_tensor, the banner flush — with a world of one.  Exactly one JSON line, the last thing on stdout."""
+    import os
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
+           "--no-cpu-baseline", "--min-seconds", "0.2"]
+    d = _run_bench(cmd, {"PCL_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29579"})
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["devices_visible"] >= 1 and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # cfg 1 at 2 poses per launch was never profiled with counters: the run must say so instead of borrowing numbers
+    assert r["traffic"] is None and r["hbm_measured"] is None and r["valu"] is None and "cfg1" in r["traffic_key"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N with fewer than N visible devices (RCCL needs one GPU per rank): a clear message, no hang."""
     import os
     import subprocess
     import sys
     from conftest import REPO
-    env = dict(os.environ, PCL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", "cfg1", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]             # rank 0 prints exactly one JSON line
-    d = js.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "candidate-poses/s"
-    assert d["value"] > 0 and abs(d["value"] - 1 * 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
-    assert d["median_t_err_m"] < 0.1 and "roofline" in d and d["vs_baseline"] is None
+    n = torch.cuda.device_count()
+    env = dict(os.environ, WORLD_SIZE=str(n + 1), RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "visible" in (out.stderr + out.stdout)
 
 
 def test_warp_from_img_matches_golden_samples():

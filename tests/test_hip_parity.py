@@ -13,18 +13,7 @@ from conftest import Cfg, load_golden
 pytestmark = pytest.mark.gpu
 
 
-def rel(a, b):
-    """max |a-b| / max |b|; NaNs must sit at the same places (0/0 losses of fully masked poses) and are then ignored."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    assert np.array_equal(np.isnan(a), np.isnan(b)), (a, b)
-    ok = ~np.isnan(b)
-    if not ok.any():
-        return 0.0
-    return np.abs(a[ok] - b[ok]).max() / max(np.abs(b[ok]).max(), 1e-30)
-
-
-def T(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+from parity_helpers import T, _check_vs_oracle, _oracle_pair, rel  # noqa: E402,F401
 
 
 @pytest.fixture(scope="module")
@@ -100,30 +89,36 @@ def _loss(ops, xyz, rgb, img, trans, rot, grad=True, sort=True, fmt="auto"):
 
 @pytest.mark.parametrize("fmt", ["auto", "u8", "f32"])
 @pytest.mark.parametrize("sort", [False, True])
-def test_sampling_loss_golden(ops, sort, fmt):
+def test_sampling_loss_golden(ops, parity, sort, fmt):
     """G3: 6 poses on the 4096-point scene, vs the reference's fp64 autograd (the exact answer) and fp32 run; fp16-level
-    texels (auto: the golden panorama is k/255), RGBA8 texels and float4 texels."""
+    texels (auto: the golden panorama is k/255), RGBA8 texels and float4 texels.
+    Bounds = measured on MI355X (loss 6e-8..1e-7, gradients 6.5e-7..7.0e-7, tools/grad_error.py) with a 2-3x margin; the
+    reference's OWN fp32 autograd is 2.8e-7 / 3.5e-6 / 2.9e-6 away from its fp64 run on these inputs, so the kernel is
+    asserted to be closer to the exact answer than the reference's fp32 path is."""
     g = load_golden("g3_sampling_loss.npz")
     out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort, fmt=fmt)
-    assert rel(out[:, 0], g["loss_f64"]) <= 2e-6
-    # gradient: the reference's own fp32-vs-fp64 gap is the yardstick for what fp32 evaluation can deliver
+    gap_l = rel(g["loss_f32"], g["loss_f64"])
     gap_t, gap_r = rel(g["grad_t_f32"], g["grad_t_f64"]), rel(g["grad_ypr_f32"], g["grad_ypr_f64"])
-    assert rel(out[:, 2:5], g["grad_t_f64"]) <= max(3 * gap_t, 1e-4)
-    assert rel(out[:, 5:8], g["grad_ypr_f64"]) <= max(3 * gap_r, 1e-4)
-    assert rel(out[:, 2:5], g["grad_t_f32"]) <= 3e-4
-    assert rel(out[:, 5:8], g["grad_ypr_f32"]) <= 3e-4
+    parity("loss vs ref fp64", rel(out[:, 0], g["loss_f64"]), 3e-7, gap_l)
+    parity("grad_t vs ref fp64", rel(out[:, 2:5], g["grad_t_f64"]), 2e-6, gap_t)
+    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 2e-6, gap_r)
+    assert 2e-6 < gap_t and 2e-6 < gap_r                   # (the bound really is below the reference's own fp32 gap)
+    # against the reference's fp32 run the distance is that run's own error
+    parity("grad_t vs ref fp32", rel(out[:, 2:5], g["grad_t_f32"]), 1.5 * gap_t, gap_t)
+    parity("grad_ypr vs ref fp32", rel(out[:, 5:8], g["grad_ypr_f32"]), 1.5 * gap_r, gap_r)
 
 
-def test_batch_sampling_loss_golden(ops):
+def test_batch_sampling_loss_golden(ops, parity):
+    """G4 (BatchSamplingLoss, B = 4, reference autograd): measured 8.9e-8 / 6.4e-7 / 6.6e-7 (reference fp32: 2.7e-7 / 3.4e-6 / 2.7e-6)."""
     s, g = load_golden("g3_sampling_loss.npz"), load_golden("g4_batch_sampling_loss.npz")
     out = _loss(ops, s["xyz"], s["rgb"], s["img"], g["trans"], g["rot"])
-    assert rel(out[:, 0], g["loss_list_f64"]) <= 2e-6
-    assert abs(out[:, 0].sum() - g["loss_f64"]) <= 1e-5
-    assert rel(out[:, 2:5], g["grad_t_f64"]) <= 1e-4
-    assert rel(out[:, 5:8], g["grad_ypr_f64"]) <= 1e-4
+    parity("loss_list vs ref fp64", rel(out[:, 0], g["loss_list_f64"]), 3e-7, rel(g["loss_list_f32"], g["loss_list_f64"]))
+    parity("sum(loss_list) vs ref fp64 (abs)", abs(out[:, 0].astype(np.float64).sum() - g["loss_f64"]), 5e-7)
+    parity("grad_t vs ref fp64", rel(out[:, 2:5], g["grad_t_f64"]), 2e-6, rel(g["grad_t_f32"], g["grad_t_f64"]))
+    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 2e-6, rel(g["grad_ypr_f32"], g["grad_ypr_f64"]))
 
 
-def test_pano_format_selection_and_float_image(ops, oracle):
+def test_pano_format_selection_and_float_image(ops, oracle, parity):
     """An image that is not k/255 must take the float4 texel path (auto-detected) and still match the oracle."""
     from piccolo_amd import synth
     n, H, W, B = 20_000, 96, 192, 4
@@ -139,22 +134,22 @@ def test_pano_format_selection_and_float_image(ops, oracle):
         ops.Pano(T(img), fmt="bf16")
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=31)
     out = _loss(ops, xyz, rgb, img_f, trans, rot)
-    ref = oracle.sampling_loss(xyz, rgb, img_f, trans, rot, dtype=np.float64)
-    assert np.abs(out[:, 1] - ref["count"]).max() <= 2
-    assert rel(out[:, 0], ref["loss"]) <= 1e-5
-    assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+    r64, r32 = _oracle_pair(oracle, xyz, rgb, img_f, trans, rot)
+    _check_vs_oracle(parity, out, r64, r32, n, "float4 texels: ")
     # the texel formats agree with each other on a k/255 image: fp16-level and RGBA8 texels bit for bit (same real
     # operands into the same fp32 fmas), float4 texels up to the rounding of the lerp
     a, b = _loss(ops, xyz, rgb, img, trans, rot, fmt="f16"), _loss(ops, xyz, rgb, img, trans, rot, fmt="f32")
     u = _loss(ops, xyz, rgb, img, trans, rot, fmt="u8")
     assert np.array_equal(a.view(np.uint32), u.view(np.uint32))
-    assert np.array_equal(a[:, 1], b[:, 1]) and rel(a[:, 0], b[:, 0]) <= 1e-6 and rel(a[:, 2:], b[:, 2:]) <= 1e-4
+    assert np.array_equal(a[:, 1], b[:, 1])
+    parity("f16-level vs float4 texels: loss", rel(a[:, 0], b[:, 0]), 3e-7)
+    parity("f16-level vs float4 texels: grad", rel(a[:, 2:], b[:, 2:]), 2e-5)
 
 
 @pytest.mark.parametrize("n,H,W,B", [(1, 64, 128, 1), (255, 64, 128, 3), (257, 16, 32, 2), (10_000, 128, 256, 5),
                                      (100_000, 256, 512, 1), (200_003, 256, 512, 8), (50_021, 101, 203, 5),
                                      (513, 7, 9, 2), (1025, 300, 100, 4)])
-def test_sampling_loss_vs_oracle(ops, oracle, n, H, W, B):
+def test_sampling_loss_vs_oracle(ops, oracle, parity, n, H, W, B):
     """Ragged sizes (n not a multiple of the block, B odd / even / multiple of 4, H < 100 so border taps occur)."""
     from piccolo_amd import synth
     xyz, rgb = synth.box_room(n, seed=n)
@@ -162,18 +157,10 @@ def test_sampling_loss_vs_oracle(ops, oracle, n, H, W, B):
     img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=n)
     out = _loss(ops, xyz, rgb, img, trans, rot)
-    ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64)
-    ref32 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float32)
+    r64, r32 = _oracle_pair(oracle, xyz, rgb, img, trans, rot)
     # count: points whose sampled colour is exactly black; a pixel-boundary flip between fp32 and fp64 evaluation can
     # move a handful of points in or out
-    dcount = np.abs(out[:, 1] - ref["count"]).max()
-    assert dcount <= max(2, 2e-5 * n)
-    # a point that flips between masked and kept moves the mean loss (and the gradient) by ~1/n of its scale
-    assert rel(out[:, 0], ref["loss"]) <= 1e-5 + 2.0 * dcount / n
-    gap = max(rel(ref32["grad_t"], ref["grad_t"]), rel(ref32["grad_ypr"], ref["grad_ypr"]))
-    tol = (max(3 * gap, 2e-4) if n >= 255 else 1e-2) + 20.0 * dcount / n
-    assert rel(out[:, 2:5], ref["grad_t"]) <= tol
-    assert rel(out[:, 5:8], ref["grad_ypr"]) <= tol
+    _check_vs_oracle(parity, out, r64, r32, n)
 
 
 def test_forward_only_matches_grad_pass(ops):
@@ -191,7 +178,7 @@ def test_all_masked_gives_nan(ops):
     assert np.isnan(out[:, 0]).all() and (out[:, 1] == 0).all()
 
 
-def test_visible_mask(ops, oracle):
+def test_visible_mask(ops, oracle, parity):
     from piccolo_amd import synth
     n, B = 5000, 4
     xyz, rgb = synth.box_room(n, 4)
@@ -201,10 +188,8 @@ def test_visible_mask(ops, oracle):
     vis = (np.random.default_rng(4).random((B, n)) < 0.7).astype(np.uint8)
     cloud, pano = ops.Cloud(T(xyz), T(rgb), sort=False), ops.Pano(T(img))
     out = ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=True, visible=T(vis)).cpu().numpy()
-    ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64, visible=vis)
-    assert np.abs(out[:, 1] - ref["count"]).max() <= 1
-    assert rel(out[:, 0], ref["loss"]) <= 1e-5
-    assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+    r64, r32 = _oracle_pair(oracle, xyz, rgb, img, trans, rot, visible=vis)
+    _check_vs_oracle(parity, out, r64, r32, n)
 
 
 def test_trim_input_loss_golden(ops):
@@ -224,17 +209,17 @@ def _gd_hist(ops, g, mode_batch, trans, rot, n_it, cfg):
     return hist.cpu().numpy(), gd.result().cpu().numpy()
 
 
-def test_gd_batch_first_iterations_match_reference(ops):
+def test_gd_batch_first_iterations_match_reference(ops, parity):
     """Free-running on-device GD vs the reference trajectory: parity <= 1e-4 holds for the first iterations only (the
     trajectory is chaotic: the reference disagrees with itself by 1e-3 after 100 iterations when only the point
     order changes)."""
     g = load_golden("g5_trajectories.npz")
     cfg = Cfg(**json.loads(str(g["cfg"])))
     hist, res = _gd_hist(ops, g, True, g["trans0"], g["rot0"], 3, cfg)
-    assert np.abs(hist - g["bat_fwd_loss"][:3]).max() <= 2e-5
+    parity("loss of iterations 0-2 vs reference (abs)", np.abs(hist - g["bat_fwd_loss"][:3]).max(), 2e-5)
     # after 3 iterations: forward pose = what iteration 3 of the reference saw
-    assert np.abs(res[:, 0:3] - g["bat_fwd_trans"][3]).max() <= 1e-4
-    assert np.abs(res[:, 3:6] - g["bat_fwd_rot"][3]).max() <= 1e-4
+    parity("translation after 3 iterations vs reference (abs, m)", np.abs(res[:, 0:3] - g["bat_fwd_trans"][3]).max(), 1e-4)
+    parity("yaw/pitch/roll after 3 iterations vs reference (abs, rad)", np.abs(res[:, 3:6] - g["bat_fwd_rot"][3]).max(), 1e-4)
 
 
 def test_gd_batch_clamp_lag(ops):
@@ -294,7 +279,7 @@ def test_gd_on_device_equals_oracle_loop_driven_by_hip_gradients(ops, oracle, mo
         assert np.float32(opt.lr) == res[b, 13], (b, opt.lr, res[b, 13])
 
 
-def test_gd_epilogue_teacher_forced_single_steps(ops, oracle):
+def test_gd_epilogue_teacher_forced_single_steps(ops, oracle, parity):
     """One on-device iteration from every recorded reference state would need state injection; instead run both loops
     for 1 iteration from 16 random starts and compare the update bit-for-bit-ish (<= 1 ulp of the parameters)."""
     from oracle import gd as ogd
@@ -313,7 +298,8 @@ def test_gd_epilogue_teacher_forced_single_steps(ops, oracle):
     it, ir = trans.copy(), rot.copy()
     ogd.omniloc_batch(g["img"], g["xyz"], g["rgb"], it, ir, cfg, loss_grad=hip_loss_grad)
     _, res = _gd_hist(ops, g, True, trans, rot, 1, cfg)
-    assert np.abs(res[:, 6:9] - it).max() <= 2e-7 and np.abs(res[:, 9:12] - ir).max() <= 2e-7
+    parity("one Adam step, translation vs oracle optimiser (abs)", np.abs(res[:, 6:9] - it).max(), 2e-7)
+    parity("one Adam step, angles vs oracle optimiser (abs)", np.abs(res[:, 9:12] - ir).max(), 2e-7)
 
 
 # --------------------------------------------------------------------------------------- reference call surface
@@ -352,7 +338,38 @@ def test_omniloc_sequential_surface(ops):
     assert t_err <= t_ref + 0.05
 
 
-def test_modules_autograd(ops):
+def test_sampling_loss_function_surface(ops, parity):
+    """omniloc.sampling_loss (omniloc.py:105-157): the forward-only duplicate of SamplingLoss that localize.py imports.
+    return_list=True -> [translation (3,1), R (3,3), loss ()], return_list=False -> loss; pinned to G3 (the reference's
+    fp64 / fp32 SamplingLoss values at the same poses) for every starting point."""
+    from piccolo_amd import omniloc as po
+    g = load_golden("g3_sampling_loss.npz")
+    img, xyz, rgb = T(g["img"]), T(g["xyz"]), T(g["rgb"])
+    it, ir = T(g["trans"].copy()), T(g["rot"].copy())
+    losses = []
+    for sp in range(len(g["trans"])):
+        res = po.sampling_loss(img, xyz, rgb, it, ir, sp, Cfg(), return_list=True)
+        assert [tuple(r.shape) for r in res] == [(3, 1), (3, 3), ()]
+        assert all(r.device.type == "cpu" and r.dtype == torch.float32 and not r.requires_grad for r in res)
+        assert np.array_equal(res[0].numpy().reshape(3), g["trans"][sp])
+        R = res[1].numpy().astype(np.float64)
+        assert np.abs(R @ R.T - np.eye(3)).max() <= 1e-6
+        alone = po.sampling_loss(img, xyz, rgb, it, ir, sp, Cfg(), return_list=False)
+        assert alone.shape == () and float(alone) == float(res[2])
+        losses.append(float(res[2]))
+    parity("loss vs ref fp64, 6 starting points", rel(losses, g["loss_f64"]), 3e-7, rel(g["loss_f32"], g["loss_f64"]))
+    # the caller's tensors are read, not modified (the reference only builds views of them, omniloc.py:109-113)
+    assert np.array_equal(it.cpu().numpy(), g["trans"]) and np.array_equal(ir.cpu().numpy(), g["rot"])
+    # R is rot_from_ypr of the starting rotation (omniloc.py:123-139)
+    Rref = ops.rot_from_ypr(ir).cpu().numpy()
+    assert np.abs(po.sampling_loss(img, xyz, rgb, it, ir, 2, Cfg())[1].numpy() - Rref[2]).max() <= 1e-7
+    # CPU tensors are accepted too (the harness may run on either device, localize.py:124)
+    cpu = po.sampling_loss(torch.from_numpy(g["img"]), torch.from_numpy(g["xyz"]), torch.from_numpy(g["rgb"]),
+                           torch.from_numpy(g["trans"].copy()), torch.from_numpy(g["rot"].copy()), 1, Cfg(), return_list=False)
+    assert float(cpu) == losses[1]
+
+
+def test_modules_autograd(ops, parity):
     """SamplingLoss / BatchSamplingLoss are differentiable modules: .backward() fills the pose leaves' .grad with the
     gradients of G3/G4."""
     from piccolo_amd import omniloc as po
@@ -363,18 +380,18 @@ def test_modules_autograd(ops):
     y, p, r = [T(g["rot"][1, k:k + 1]).requires_grad_() for k in range(3)]
     loss = mod(t, y, p, r)
     loss.backward()
-    assert abs(loss.item() - g["loss_f64"][1]) <= 2e-6
-    assert rel(t.grad.cpu().numpy().reshape(3), g["grad_t_f64"][1]) <= 1e-4
-    assert rel([y.grad.item(), p.grad.item(), r.grad.item()], g["grad_ypr_f64"][1]) <= 1e-4
+    parity("SamplingLoss: loss vs ref fp64 (abs)", abs(loss.item() - g["loss_f64"][1]), 1e-7)
+    parity("SamplingLoss: t.grad vs ref fp64", rel(t.grad.cpu().numpy().reshape(3), g["grad_t_f64"][1]), 2e-6)
+    parity("SamplingLoss: ypr.grad vs ref fp64", rel([y.grad.item(), p.grad.item(), r.grad.item()], g["grad_ypr_f64"][1]), 2e-6)
     B = 4
     bm = po.BatchSamplingLoss(xyz, rgb, img, xyz.device, Cfg(num_input=B))
     tb = T(g4["trans"]).unsqueeze(-1).requires_grad_()
     yb, pb, rb = [T(g4["rot"][:, k:k + 1]).requires_grad_() for k in range(3)]
     total, lst = bm(tb, yb, pb, rb)
     total.backward()
-    assert rel(lst.detach().cpu().numpy(), g4["loss_list_f64"]) <= 2e-6
-    assert rel(tb.grad.squeeze(-1).cpu().numpy(), g4["grad_t_f64"]) <= 1e-4
-    assert rel(torch.cat([yb.grad, pb.grad, rb.grad], 1).cpu().numpy(), g4["grad_ypr_f64"]) <= 1e-4
+    parity("BatchSamplingLoss: loss_list vs ref fp64", rel(lst.detach().cpu().numpy(), g4["loss_list_f64"]), 3e-7)
+    parity("BatchSamplingLoss: t.grad vs ref fp64", rel(tb.grad.squeeze(-1).cpu().numpy(), g4["grad_t_f64"]), 2e-6)
+    parity("BatchSamplingLoss: ypr.grad vs ref fp64", rel(torch.cat([yb.grad, pb.grad, rb.grad], 1).cpu().numpy(), g4["grad_ypr_f64"]), 2e-6)
 
 
 # --------------------------------------------------------------------------------------- z-buffer ops
@@ -460,7 +477,7 @@ def test_degenerate_points_match_oracle(ops, oracle):
         assert np.abs(out[0, 2:] - g_ref).max() <= 2e-3 * scale, (k, out[0, 2:], g_ref)
 
 
-def test_large_batch_and_odd_batch(ops, oracle):
+def test_large_batch_and_odd_batch(ops, oracle, parity):
     """B = 1800 (a trim_input_loss table, forward only), B = 7 (odd: one pose per block) and B = 6 against the oracle."""
     from piccolo_amd import synth
     n, H, W = 30_000, 96, 192
@@ -470,13 +487,16 @@ def test_large_batch_and_odd_batch(ops, oracle):
     for B, grad in ((1800, False), (7, True), (6, True)):
         trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=B, sigma_t=1.0, sigma_r=1.0)
         out = _loss(ops, xyz, rgb, img, trans, rot, grad=grad)
-        ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64, grad=grad)
-        assert np.abs(out[:, 1] - ref["count"]).max() <= 2
-        # a point whose sample sits within an ulp of a black/non-black pixel boundary may be masked in fp32 and not in
-        # fp64 (count differs by <= 2): that moves the mean by up to ~3/n
-        assert rel(out[:, 0], ref["loss"]) <= 1e-5 + 3.0 / n
         if grad:
-            assert rel(out[:, 2:5], ref["grad_t"]) <= 3e-4 and rel(out[:, 5:8], ref["grad_ypr"]) <= 3e-4
+            r64, r32 = _oracle_pair(oracle, xyz, rgb, img, trans, rot)
+            _check_vs_oracle(parity, out, r64, r32, n, "B=%d: " % B)
+        else:
+            ref = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64, grad=False)
+            dcount = float(np.abs(out[:, 1] - ref["count"]).max())
+            parity("B=%d forward only: count (points)" % B, dcount, 2)
+            # a point whose sample sits within an ulp of a black/non-black pixel boundary may be masked in fp32 and not
+            # in fp64: that moves the mean by ~1/n per point
+            parity("B=%d forward only: loss vs fp64" % B, rel(out[:, 0], ref["loss"]), 3e-7 + 2.0 * dcount / n)
 
 
 def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
@@ -578,14 +598,14 @@ def test_multi_image_launch_equals_per_image_runs(ops, oracle):
         gd.set_panos([ops.Pano(T(np.zeros((32, 64, 3), np.float32)))] * (I * B))
 
 
-def test_gd_sequential_first_iterations_match_reference(ops):
+def test_gd_sequential_first_iterations_match_reference(ops, parity):
     """omniloc's sequential mode, free-running on the device, vs the reference's recorded trajectory (G5 seq0)."""
     g = load_golden("g5_trajectories.npz")
     cfg = Cfg(**json.loads(str(g["cfg"])))
     hist, res = _gd_hist(ops, g, False, g["trans0"][0:1], g["rot0"][0:1], 3, cfg)
-    assert np.abs(hist[:, 0] - g["seq0_fwd_loss"][:3, 0]).max() <= 2e-5
-    assert np.abs(res[0, 0:3] - g["seq0_fwd_trans"][3, 0]).max() <= 1e-4
-    assert np.abs(res[0, 3:6] - g["seq0_fwd_rot"][3, 0]).max() <= 1e-4
+    parity("loss of iterations 0-2 vs reference (abs)", np.abs(hist[:, 0] - g["seq0_fwd_loss"][:3, 0]).max(), 2e-5)
+    parity("translation after 3 iterations vs reference (abs, m)", np.abs(res[0, 0:3] - g["seq0_fwd_trans"][3, 0]).max(), 1e-4)
+    parity("yaw/pitch/roll after 3 iterations vs reference (abs, rad)", np.abs(res[0, 3:6] - g["seq0_fwd_rot"][3, 0]).max(), 1e-4)
 
 
 def test_end_to_end_pose_inside_reference_self_noise_band(ops):
@@ -608,6 +628,32 @@ def test_end_to_end_pose_inside_reference_self_noise_band(ops):
     # and the recovered pose itself is within the reference's run-to-run spread of the reference's pose
     spread = max(float(g["self_noise"][:, 2].max()), 1e-3)
     assert np.abs(res[0].numpy() - g["ret_t"]).max() <= 5 * spread, (np.abs(res[0].numpy() - g["ret_t"]).max(), spread)
+
+
+def test_end_to_end_32_seeds_as_close_to_the_reference_as_it_is_to_itself(ops, oracle, parity):
+    """G18: the reference's full 100-iteration refinements of 32 scenes, each also rerun by the reference with the points
+    permuted (its fp32 self-noise: t-err moves by 6e-4 m in the median, the recovered translation by 1.1e-3 m).  The
+    free-running on-device GD must land as close to the reference as the reference lands to itself — the end-to-end
+    statement of parity for a chaotic trajectory: sequential omniloc on all 32, omniloc_batch (4 starts)
+    on the 8 scenes the reference ran in batch mode."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    from test_oracle_golden import g18_compare, g18_scene
+    g = load_golden("g18_end_to_end_seeds.npz")
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=4)
+    rows, rows_b = [], []
+    for s in range(g["seq"].shape[0]):
+        xyz, rgb, img, trans, rot, t_gt, R_gt = g18_scene(oracle, g, s)
+        X, C, I = T(xyz), T(rgb), T(img)
+        r = po.omniloc(I, X, C, T(trans.copy()), T(rot.copy()), 0, cfg, {})
+        t, R = r[0].numpy().reshape(3), r[1].numpy()
+        rows.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+        if s < g["batch"].shape[0]:
+            r = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), cfg, {})
+            t, R = r[0].numpy().reshape(3), r[1].numpy()
+            rows_b.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+    g18_compare(np.array(rows), g["seq"], lambda q, a, b, y=None: parity("omniloc: " + q, a, b, y))
+    g18_compare(np.array(rows_b), g["batch"], lambda q, a, b, y=None: parity("omniloc_batch: " + q, a, b, y))
 
 
 def test_cloud_order_is_a_morton_sorted_permutation(ops):

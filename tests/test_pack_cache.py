@@ -1,0 +1,58 @@
+"""Host logic of the pack cache (piccolo_amd/omniloc.py): per-kind LRU keyed by tensor identity.  No GPU needed — the
+cached objects are stand-ins."""
+import gc
+
+import torch
+
+from piccolo_amd import omniloc as po
+
+
+def test_lru_per_kind_keeps_the_room_while_images_stream_through():
+    po._cache.clear()
+    xyz, rgb = torch.zeros(10, 3), torch.zeros(10, 3)
+    made = []
+
+    def make(tag):
+        def f():
+            made.append(tag)
+            return object()
+        return f
+    cloud = po._cached("cloud", (xyz, rgb), make("cloud"))
+    box = po._cached("box", (xyz,), make("box"), sub=0.05)
+    grid = po._cached("grid", (xyz,), make("grid"), sub="cfg-a")
+    imgs = [torch.zeros(4, 8, 3) for _ in range(40)]          # far more query images than any capacity
+    for im in imgs:
+        po._cached("pano", (im,), make("pano"))
+        po._cached("pano_u8", (im,), make("pano_u8"))
+    # the cloud-side entries survived the stream of panoramas
+    assert po._cached("cloud", (xyz, rgb), make("again")) is cloud
+    assert po._cached("box", (xyz,), make("again"), sub=0.05) is box
+    assert po._cached("grid", (xyz,), make("again"), sub="cfg-a") is grid
+    assert "again" not in made
+    assert len(po._cache.kinds["pano"]) == po._CAPACITY["pano"] and len(po._cache.kinds["pano_u8"]) == po._CAPACITY["pano_u8"]
+    # least recently used goes first: the last image is still there, the first is not
+    n = len(made)
+    po._cached("pano", (imgs[-1],), make("hit"))
+    assert len(made) == n
+    po._cached("pano", (imgs[0],), make("miss"))
+    assert made[-1] == "miss"
+
+
+def test_sub_keys_versions_and_dead_tensors():
+    po._cache.clear()
+    xyz = torch.zeros(10, 3)
+    a = po._cached("box", (xyz,), object, sub=0.05)
+    b = po._cached("box", (xyz,), object, sub=0.1)
+    assert a is not b and po._cached("box", (xyz,), object, sub=0.05) is a
+    xyz.add_(1.0)                                              # in-place edit bumps the version: a new entry
+    assert po._cached("box", (xyz,), object, sub=0.05) is not a
+    # entries of dead tensors are purged on the next insertion (their address may be reused)
+    tmp = torch.zeros(5, 3)
+    po._cached("box", (tmp,), object, sub=0.05)
+    del tmp
+    gc.collect()
+    keep = torch.ones(7, 3)
+    po._cached("box", (keep,), object, sub=0.05)
+    shapes = [k[1][1] for k in po._cache.kinds["box"]]
+    assert (5, 3) not in shapes and (7, 3) in shapes
+    assert len(po._cache.kinds["box"]) <= po._CAPACITY["box"]
