@@ -12,6 +12,7 @@
 
 typedef float pcl_f4 __attribute__((ext_vector_type(4)));
 typedef int pcl_i4 __attribute__((ext_vector_type(4)));
+typedef int pcl_i2 __attribute__((ext_vector_type(2)));
 
 // One candidate pose as the loss kernel consumes it (scalar loads): p = R (x - t).
 struct PclPoseRec {
@@ -177,7 +178,6 @@ __device__ inline __amdgpu_buffer_rsrc_t pcl_tex_rsrc(const void* pano, int H, i
 // bytes per texel of a packed panorama format
 __host__ __device__ constexpr int pcl_texel_bytes(int fmt) { return fmt == PCL_PANO_U8 ? 4 : fmt == PCL_PANO_F16 ? 8 : 16; }
 
-typedef int pcl_i2 __attribute__((ext_vector_type(2)));
 // two horizontally adjacent RGBA8 texels in one 8-byte load
 __device__ inline pcl_i2 pcl_texel_pair_u8(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {
@@ -195,18 +195,51 @@ __device__ inline pcl_f4 pcl_texel(__amdgpu_buffer_rsrc_t rsrc, int voff, int so
     return __builtin_bit_cast(pcl_f4, v);
 }
 
-__device__ inline float pcl_wave_sum(float v)
+// Sum over the 64 lanes of a wave, returned in every lane.  Data-parallel-primitive moves inside the rows of 16 lanes
+// (v_add_f32_dpp: no LDS, no waitcnt), then the four row sums through v_readlane.  (__shfl_xor compiles to ds_bpermute_b32 +
+// s_waitcnt lgkmcnt(0) per step: 6 dependent LDS round trips per value — measured 4.9 us per block for the 14 sums of
+// the loss kernel's epilogue, tools/block_trace.py; this form is ~0.3 us.)
+template <int CTRL>
+__device__ __forceinline__ float pcl_dpp(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float pcl_wave_sum(float v)
+{
+    v += pcl_dpp<0xB1>(v);       // quad_perm [1,0,3,2]: neighbour
+    v += pcl_dpp<0x4E>(v);       // quad_perm [2,3,0,1]: other pair of the quad
+    v += pcl_dpp<0x141>(v);      // row_half_mirror: the other quad of the 8
+    v += pcl_dpp<0x140>(v);      // row_mirror: the other half of the row -> every lane holds its row's sum
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
-__device__ inline double pcl_wave_sum_d(double v)
+// the same for a double (the GD epilogue's second-stage sums): the two dwords move separately, the add is v_add_f64
+template <int CTRL>
+__device__ __forceinline__ double pcl_dpp_d(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    pcl_i2 w = __builtin_bit_cast(pcl_i2, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, CTRL, 0xf, 0xf, true);
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, w);
+}
+__device__ __forceinline__ double pcl_readlane_d(double v, int lane)
+{
+    pcl_i2 w = __builtin_bit_cast(pcl_i2, v);
+    w.x = __builtin_amdgcn_readlane(w.x, lane);
+    w.y = __builtin_amdgcn_readlane(w.y, lane);
+    return __builtin_bit_cast(double, w);
+}
+__device__ __forceinline__ double pcl_wave_sum_d(double v)
+{
+    v += pcl_dpp_d<0xB1>(v);
+    v += pcl_dpp_d<0x4E>(v);
+    v += pcl_dpp_d<0x141>(v);
+    v += pcl_dpp_d<0x140>(v);
+    return (pcl_readlane_d(v, 0) + pcl_readlane_d(v, 16)) + (pcl_readlane_d(v, 32) + pcl_readlane_d(v, 48));
 }
 
 // hipError_t passthrough for launch wrappers

@@ -37,10 +37,29 @@ struct PclLossArgs {
     float* partials;         // [nchunks][B][8]
     int nchunks;             // multiple of 8
     int ngroups;             // B / G
-    int64_t chunk_len;       // multiple of PCL_STEP
+    int steps_base, steps_rem;   // the cloud's ceil(n / PCL_STEP) steps are dealt out evenly: chunk c has steps_base + (c < steps_rem)
 };
 
 #define PCL_STEP (2 * PCL_BLOCK)   // points per block iteration: two per lane
+
+// Experiments only (tools/block_trace.py builds a second library with -DPCL_BLOCK_TRACE): every block records when it
+// FINISHED (100 MHz s_memrealtime) and where it ran (HW_ID, XCC_ID).  Only the end: a timestamp taken at the start has to
+// live somewhere for the whole block, and this kernel sits exactly at its 4-waves-per-SIMD register budget — with start
+// stamps the allocator falls back to 160 VGPRs / 3 waves and the timeline is no longer the product's.
+#ifdef PCL_BLOCK_TRACE
+__device__ unsigned long long* pcl_trace_buf = nullptr;
+extern "C" int pcl_debug_set_block_trace(unsigned long long* buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcl_trace_buf), &buf, sizeof(buf));
+}
+#define PCL_TRACE_NOW() __builtin_amdgcn_s_memrealtime()
+__global__ void pcl_debug_stamp_kernel(unsigned long long* slot) { *slot = PCL_TRACE_NOW(); }
+extern "C" int pcl_debug_stamp(unsigned long long* slot, void* stream)
+{
+    hipLaunchKernelGGL(pcl_debug_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+    return (int)hipGetLastError();
+}
+#endif
 
 __device__ __forceinline__ f2 pcl_fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -339,8 +358,16 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
         for (int k = 0; k < PCL_NACC; k++) acc[g][k] = F2(0.f);
     }
 
-    const int begin = (int)((int64_t)chunk * a.chunk_len);
-    int end = begin + (int)a.chunk_len;
+    // balanced at step granularity: uniform chunks of ceil(n / nchunks) points rounded up to whole steps leave the last
+    // chunks empty (1M points in 256 chunks: 4096-point chunks, the last 12 empty — one XCD finished 30 % early while the
+    // other seven carried 5 % more than their share, tools/block_trace.py)
+    int first = chunk * a.steps_base + min(chunk, a.steps_rem);
+    int nsteps = a.steps_base + (chunk < a.steps_rem ? 1 : 0);
+    // (Measured and rejected: giving neighbouring work items different lengths — chunk pairs with their boundary moved by
+    // 1/8..3/8 of a chunk — so that blocks resident together do not run their prologues / epilogues in phase: monotonically
+    // slower, 124 -> 131 -> 137 us at cfg 2 for shifts of 1 / 2 steps: the longest block sets the tail.)
+    const int begin = first * PCL_STEP;
+    int end = begin + nsteps * PCL_STEP;
     if (end > (int)a.n) end = (int)a.n;
     const int last = (int)a.n - 1;
 
@@ -420,6 +447,15 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
         if (GRAD || k < 2) s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         a.partials[((int64_t)chunk * a.B + pose0 + g) * PCL_NACC + k] = s;
     }
+#ifdef PCL_BLOCK_TRACE
+    if (pcl_trace_buf && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* t = pcl_trace_buf + (size_t)blockIdx.x * 4;
+        t[0] = 0; t[1] = 0; t[2] = PCL_TRACE_NOW(); t[3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -434,7 +470,7 @@ static int pcl_env_int(const char* name, int dflt)
 
 struct PclPlan {
     int G, ngroups, nchunks;
-    int64_t chunk_len;
+    int steps_base, steps_rem;
 };
 
 static PclPlan pcl_plan(int64_t n, int B)
@@ -450,13 +486,12 @@ static PclPlan pcl_plan(int64_t n, int B)
     // sweep an eighth of the room on its own, nothing it gathers is reused by a neighbour (5.08 -> 4.83 ms at 64 chunks)
     int64_t want = blocks_env / p.ngroups;
     if (want < 64) want = 64;
-    int64_t max_chunks = (n + PCL_STEP - 1) / PCL_STEP;
-    if (want > max_chunks) want = max_chunks;
-    want = ((want + 7) / 8) * 8;
-    int64_t len = (n + want - 1) / want;
-    len = ((len + PCL_STEP - 1) / PCL_STEP) * PCL_STEP;
+    int64_t steps = (n + PCL_STEP - 1) / PCL_STEP;
+    if (want > steps) want = steps;
+    want = ((want + 7) / 8) * 8;                   // (a cloud of fewer steps than chunks leaves the surplus chunks empty)
     p.nchunks = (int)want;
-    p.chunk_len = len;
+    p.steps_base = (int)(steps / want);
+    p.steps_rem = (int)(steps % want);
     return p;
 }
 
@@ -500,7 +535,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
-    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.chunk_len = p.chunk_len;
+    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
     if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
