@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 2 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader */
+#define PCL_ABI_VERSION 3 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -157,6 +157,15 @@ int pcl_cloud2idx(const float *xyz, int64_t n, float *coord, void *stream);
 /* utils.py:64-103 sample_from_img: clip to +-0.99, bilinear, zero padding, align_corners=False; rgb_out [n][3]. */
 int pcl_sample_from_img(const void *pano, int pano_format, int H, int W, const float *coord, int64_t n, float *rgb_out,
                         void *stream);
+/* Backward of the two ops above, for callers that differentiate through them outside SamplingLoss (the reference's are plain
+ * autograd ops, utils.py:16-103):
+ *   pcl_cloud2idx_backward        grad_xyz [n][3] = J^T grad_coord [n][2]  (atan2 / norm chain rule of utils.py:44-59)
+ *   pcl_sample_from_img_backward  grad_coord [n][2] (through torch.clip and grid_sampler_2d, utils.py:96-98; nullable) and
+ *                                 grad_img [H][W][3] fp32, ACCUMULATED with float atomics into a caller-zeroed buffer
+ *                                 (nullable); grad_rgb [n][3] is the incoming gradient. */
+int pcl_cloud2idx_backward(const float *xyz, const float *grad_coord, int64_t n, float *grad_xyz, void *stream);
+int pcl_sample_from_img_backward(const void *pano, int pano_format, int H, int W, const float *coord, const float *grad_rgb,
+                                 int64_t n, float *grad_coord, float *grad_img, void *stream);
 /* utils.py:425-453 rot_from_ypr for B poses: rot [B][3] -> R [B][9] row-major. */
 int pcl_rot_from_ypr(const float *rot, int B, float *R, void *stream);
 /* utils.py:208-229 quantile on each of the 3 columns of xyz [n][3]: box[6] = x[int(n q)], x[int(n (1-q))], y.., z..

@@ -88,6 +88,33 @@ def sample_from_img(img, coord, dtype=None):
     return out.reshape(shp[:-1] + (3,))
 
 
+def cloud2idx_backward(xyz, grad_coord, dtype=None):
+    """d(sum(grad_coord * cloud2idx(xyz))) / d xyz — what autograd gives the reference's utils.cloud2idx."""
+    s, dt = _sfx(dtype or np.asarray(xyz).dtype)
+    x = _arr(xyz, dt)
+    shp = x.shape
+    x = x.reshape(-1, 3)
+    g = _arr(grad_coord, dt).reshape(-1, 2)
+    out = np.empty_like(x)
+    getattr(lib(), "orc_cloud2idx_backward" + s)(_p(x), _p(g), _i64(x.shape[0]), _p(out))
+    return out.reshape(shp)
+
+
+def sample_from_img_backward(img, coord, grad_out, dtype=None, want_img=True):
+    """(grad_coord, grad_img) of utils.sample_from_img for the incoming gradient grad_out (.., 3)."""
+    s, dt = _sfx(dtype or np.asarray(img).dtype)
+    im = _arr(img, dt)
+    c = _arr(coord, dt)
+    shp = c.shape
+    c = c.reshape(-1, 2)
+    g = _arr(grad_out, dt).reshape(-1, 3)
+    H, W, _ = im.shape
+    gc = np.empty_like(c)
+    gi = np.zeros_like(im) if want_img else None
+    getattr(lib(), "orc_sample_from_img_backward" + s)(_p(im), _int(H), _int(W), _p(c), _p(g), _i64(c.shape[0]), _p(gc), _p(gi))
+    return gc.reshape(shp), gi
+
+
 def sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float32, grad=True, visible=None, nthreads=0):
     """Loss (+ gradient) of B candidate poses.  trans (B,3), rot (B,3)=[yaw,pitch,roll].
 

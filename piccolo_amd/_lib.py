@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
@@ -68,6 +68,8 @@ SIGNATURES = {
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),
     "pcl_sample_from_img": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp]),
+    "pcl_cloud2idx_backward": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "pcl_sample_from_img_backward": (_int, [_vp, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _vp]),
     "pcl_rot_from_ypr": (_int, [_vp, _int, _vp, _vp]),
     "pcl_quantile_workspace_bytes": (_sz, []),
     "pcl_quantile_box": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp]),

@@ -22,27 +22,44 @@ extern "C" int pcl_cloud2idx(const float* xyz, int64_t n, float* coord, void* st
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------- sample_from_img
-// utils.py:64-103: clip to +-0.99, grid_sample(bilinear, zeros, align_corners=False).  Same tap arithmetic as
-// ATen's grid_sampler_2d (weights (1-fx)(1-fy) ... times the four taps) so the stand-alone op matches to rounding.
-template <int FMT>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __restrict__ pano, int H, int W,
-                                                               const float* __restrict__ coord, int64_t n,
-                                                               float* __restrict__ out)
+// Backward of cloud2idx: grad_xyz = J^T grad_coord per point — what autograd derives for utils.py:44-59 when a caller
+// composes the stand-alone op (the fused loss kernel carries its own, packed form of the same chain rule).  IEEE
+// divisions: this op is HBM-bound (32 B/point), the arithmetic is free.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_cloud2idx_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ gcoord,
+                                                                   int64_t n, float* __restrict__ gxyz)
 {
     int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
     if (i >= n) return;
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, pcl_texel_bytes(FMT));
-    float2 g = reinterpret_cast<const float2*>(coord)[i];
-    float gx = __builtin_amdgcn_fmed3f(g.x, -0.99f, 0.99f), gy = __builtin_amdgcn_fmed3f(g.y, -0.99f, 0.99f);
-    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
-    float fx0 = floorf(ix), fy0 = floorf(iy);
-    int x0 = (int)fx0 + 1, y0 = (int)fy0 + 1;                 // +1: zero border
-    // keep the gather inside the bordered texture for any input (|g| <= 0.99 already guarantees it for H,W >= 1)
-    x0 = min(max(x0, 0), W); y0 = min(max(y0, 0), H);
-    float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
-    int Wp = W + 2;
-    pcl_f4 t00, t01, t10, t11;
+    const float pi = 3.14159265358979323846f;
+    float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    float2 G = reinterpret_cast<const float2*>(gcoord)[i];
+    float a = x + 1e-6f, b = z + 1e-6f, rho = sqrtf(x * x + y * y);
+    float s1 = a * a + y * y, s2 = rho * rho + b * b;
+    float dphi = -G.x / pi, dth = 2.f * G.y / pi;              // gx = 1 - phi/pi, gy = 2 theta/pi - 1
+    float drho = dth * b / s2;
+    float rx = rho > 0.f ? x / rho : 0.f, ry = rho > 0.f ? y / rho : 0.f;      // norm backward: 0 at rho = 0
+    gxyz[3 * i] = dphi * (-y / s1) + drho * rx;
+    gxyz[3 * i + 1] = dphi * (a / s1) + drho * ry;
+    gxyz[3 * i + 2] = dth * (-rho / s2);
+}
+
+extern "C" int pcl_cloud2idx_backward(const float* xyz, const float* grad_coord, int64_t n, float* grad_xyz, void* stream)
+{
+    if (!xyz || !grad_coord || !grad_xyz || n <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_cloud2idx_bwd_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, xyz, grad_coord, n, grad_xyz);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- sample_from_img
+// utils.py:64-103: clip to +-0.99, grid_sample(bilinear, zeros, align_corners=False).  Same tap arithmetic as
+// ATen's grid_sampler_2d (weights (1-fx)(1-fy) ... times the four taps) so the stand-alone op matches to rounding.
+// the four taps of a footprint as the fp32 colours the reference samples (level formats: k / 255 by IEEE division)
+template <int FMT>
+__device__ __forceinline__ void pcl_fetch_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, pcl_f4& t00, pcl_f4& t01,
+                                               pcl_f4& t10, pcl_f4& t11)
+{
     if (FMT == PCL_PANO_U8) {
         // levels back to the fp32 values the reference samples: k / 255 (IEEE division, as uint8 -> .float() / 255.)
         int voff = (y0 * Wp + x0) * 4;
@@ -66,6 +83,27 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __res
         t00 = pcl_texel(tex, voff, 0); t01 = pcl_texel(tex, voff + 16, 0);
         t10 = pcl_texel(tex, voff, row); t11 = pcl_texel(tex, voff + 16, row);
     }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_kernel(const void* __restrict__ pano, int H, int W,
+                                                               const float* __restrict__ coord, int64_t n,
+                                                               float* __restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, pcl_texel_bytes(FMT));
+    float2 g = reinterpret_cast<const float2*>(coord)[i];
+    float gx = __builtin_amdgcn_fmed3f(g.x, -0.99f, 0.99f), gy = __builtin_amdgcn_fmed3f(g.y, -0.99f, 0.99f);
+    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    int x0 = (int)fx0 + 1, y0 = (int)fy0 + 1;                 // +1: zero border
+    // keep the gather inside the bordered texture for any input (|g| <= 0.99 already guarantees it for H,W >= 1)
+    x0 = min(max(x0, 0), W); y0 = min(max(y0, 0), H);
+    float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+    int Wp = W + 2;
+    pcl_f4 t00, t01, t10, t11;
+    pcl_fetch_taps<FMT>(tex, x0, y0, Wp, t00, t01, t10, t11);
     float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
     out[3 * i] = t00.x * nw + t01.x * ne + t10.x * sw + t11.x * se;
     out[3 * i + 1] = t00.y * nw + t01.y * ne + t10.y * sw + t11.y * se;
@@ -84,6 +122,65 @@ extern "C" int pcl_sample_from_img(const void* pano, int pano_format, int H, int
         hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_F16>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
     else
         hipLaunchKernelGGL(pcl_sample_kernel<PCL_PANO_F32>, grid, dim3(PCL_BLOCK), 0, (hipStream_t)stream, pano, H, W, coord, n, rgb_out);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of sample_from_img (torch.clip -> grid_sampler_2d, utils.py:96-98): per point
+//   grad_coord = [in range] (size / 2) <grad_out, d out / d (ix, iy)>      (clamp passes the gradient on [-0.99, 0.99])
+//   grad_img[tap] += weight(tap) * grad_out                                  (float atomics, like ATen's own GPU backward;
+//                                                                             taps in the zero border are dropped)
+// Either output may be null.
+template <int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_sample_bwd_kernel(const void* __restrict__ pano, int H, int W,
+                                                                   const float* __restrict__ coord, const float* __restrict__ gout,
+                                                                   int64_t n, float* __restrict__ gcoord, float* __restrict__ gimg)
+{
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(pano, H, W, pcl_texel_bytes(FMT));
+    float2 g = reinterpret_cast<const float2*>(coord)[i];
+    const bool in_x = g.x >= -0.99f && g.x <= 0.99f, in_y = g.y >= -0.99f && g.y <= 0.99f;
+    float gx = __builtin_amdgcn_fmed3f(g.x, -0.99f, 0.99f), gy = __builtin_amdgcn_fmed3f(g.y, -0.99f, 0.99f);
+    float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    float fx0 = floorf(ix), fy0 = floorf(iy);
+    int x0 = min(max((int)fx0 + 1, 0), W), y0 = min(max((int)fy0 + 1, 0), H);      // +1: zero border
+    float wx1 = ix - fx0, wx0 = (fx0 + 1.f) - ix, wy1 = iy - fy0, wy0 = (fy0 + 1.f) - iy;
+    float go0 = gout[3 * i], go1 = gout[3 * i + 1], go2 = gout[3 * i + 2];
+    if (gcoord) {
+        pcl_f4 t00, t01, t10, t11;
+        pcl_fetch_taps<FMT>(tex, x0, y0, W + 2, t00, t01, t10, t11);
+        float dx0 = (t01.x - t00.x) * wy0 + (t11.x - t10.x) * wy1, dy0 = (t10.x - t00.x) * wx0 + (t11.x - t01.x) * wx1;
+        float dx1 = (t01.y - t00.y) * wy0 + (t11.y - t10.y) * wy1, dy1 = (t10.y - t00.y) * wx0 + (t11.y - t01.y) * wx1;
+        float dx2 = (t01.z - t00.z) * wy0 + (t11.z - t10.z) * wy1, dy2 = (t10.z - t00.z) * wx0 + (t11.z - t01.z) * wx1;
+        float sx = go0 * dx0 + go1 * dx1 + go2 * dx2, sy = go0 * dy0 + go1 * dy1 + go2 * dy2;
+        reinterpret_cast<float2*>(gcoord)[i] = make_float2(in_x ? sx * (0.5f * (float)W) : 0.f, in_y ? sy * (0.5f * (float)H) : 0.f);
+    }
+    if (gimg) {
+        const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int xx = x0 - 1 + (t & 1), yy = y0 - 1 + (t >> 1);                      // back to image coordinates
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            float* p = gimg + ((int64_t)yy * W + xx) * 3;
+            atomicAdd(p, w[t] * go0); atomicAdd(p + 1, w[t] * go1); atomicAdd(p + 2, w[t] * go2);
+        }
+    }
+}
+
+extern "C" int pcl_sample_from_img_backward(const void* pano, int pano_format, int H, int W, const float* coord, const float* grad_rgb,
+                                            int64_t n, float* grad_coord, float* grad_img, void* stream)
+{
+    if (!pano || !coord || !grad_rgb || (!grad_coord && !grad_img) || n <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
+    dim3 grid((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK));
+    hipStream_t s = (hipStream_t)stream;
+    if (pano_format == PCL_PANO_U8)
+        hipLaunchKernelGGL(pcl_sample_bwd_kernel<PCL_PANO_U8>, grid, dim3(PCL_BLOCK), 0, s, pano, H, W, coord, grad_rgb, n, grad_coord, grad_img);
+    else if (pano_format == PCL_PANO_F16)
+        hipLaunchKernelGGL(pcl_sample_bwd_kernel<PCL_PANO_F16>, grid, dim3(PCL_BLOCK), 0, s, pano, H, W, coord, grad_rgb, n, grad_coord, grad_img);
+    else
+        hipLaunchKernelGGL(pcl_sample_bwd_kernel<PCL_PANO_F32>, grid, dim3(PCL_BLOCK), 0, s, pano, H, W, coord, grad_rgb, n, grad_coord, grad_img);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -14,8 +14,9 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     is kept because callers may rely on it, see `strict_reference_asserts`);
   * two extra, optional cfg keys: depth_mask (default False = reference behaviour) multiplies the north star's
     scatter-min visibility (csrc/pcl_depth.hip) into the loss mask, depth_tau is its tolerance;
-  * cfg.visualize: the reference's frame capture is broken (`new_xyz` undefined, omniloc.py:61); here it returns
-    an empty frame list as 4th element instead of raising NameError.
+  * cfg.visualize: the reference's frame capture is broken (`new_xyz` undefined, omniloc.py:61 -> NameError); here
+    omniloc returns the frame list that code means to build (query image over the cloud rendered at the current pose,
+    per iteration) as 4th element.
 """
 import weakref
 from collections import OrderedDict
@@ -152,7 +153,11 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     gd = ops.GradientDescent(cloud, pano, input_trans[starting_point], input_rot[starting_point], box,
                              lr=lr, patience=patience, factor=factor, batch_mode=False,
                              depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
-    gd.run(num_iter)
+    frames = None
+    if vis:
+        frames = _run_with_frames(gd, img, xyz, rgb, num_iter)
+    else:
+        gd.run(num_iter)
     res = gd.result()[0]
     R = _rot_matrix(res[3:6])
     out = torch.cat([res[0:3], R.reshape(-1), res[12:13]]).cpu()
@@ -161,8 +166,34 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
         input_rot[starting_point] = res[9:12].to(input_rot.device)
     ret = [out[0:3].reshape(3, 1).clone(), out[3:12].reshape(3, 3).clone(), out[12].clone()]
     if vis:
-        ret.append([])
+        ret.append(frames)
     return ret
+
+
+def _run_with_frames(gd, img, xyz, rgb, num_iter):
+    """cfg.visualize: the frame list the reference means to build (omniloc.py:59-69, :93-100; its own code stops at the
+    undefined `new_xyz`): per iteration one PIL frame, the query image on top of the cloud rendered (make_pano, half
+    resolution) at the pose that iteration's forward used; the first frame 5 times in all, the last one 10 more times, then
+    5 frames with a black lower half.  The harness saves them as a GIF (localize.py:285-288).  Same on-device GD, one
+    iteration per call; the renders are the z-buffer kernel."""
+    import numpy as np
+    from PIL import Image
+    h, w = int(img.shape[0]) // 2, int(img.shape[1]) // 2
+    gt_img = Image.fromarray(np.uint8(ops._dev(img).cpu().numpy() * 255), "RGB").resize((w, h))
+    frames, new_frame = [], None
+    for it in range(num_iter):
+        pose = gd.result()[0]                               # the parameters this iteration's forward sees
+        gd.run(1)
+        cur = ops.make_pano(ops.transform_cloud(xyz, pose[0:3], pose[3:6]), rgb, (h, w)).cpu().numpy().astype(np.uint8)
+        new_frame = Image.new("RGB", (w, 2 * h))
+        new_frame.paste(gt_img, (0, 0))
+        new_frame.paste(Image.fromarray(cur), (0, h))
+        frames.extend([new_frame] * (5 if it == 0 else 1))
+    if new_frame is not None:
+        last_frame = Image.new("RGB", (w, 2 * h))
+        last_frame.paste(gt_img, (0, 0))
+        frames.extend([new_frame] * 10 + [last_frame] * 5)
+    return frames
 
 
 def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=None):

@@ -380,6 +380,36 @@ def sample_from_img(pano, coord):
     return out.reshape(shp[:-1] + (3,))
 
 
+def cloud2idx_backward(xyz, grad_coord):
+    """grad w.r.t. xyz (.., 3) of cloud2idx for the incoming gradient grad_coord (.., 2)."""
+    lib = _lib.load()
+    x, g = _dev(xyz), _dev(grad_coord)
+    flat, gflat = x.reshape(-1, 3), g.reshape(-1, 2)
+    if gflat.shape[0] != flat.shape[0]:
+        raise ValueError("grad_coord must have one (gx, gy) per point")
+    out = torch.empty_like(flat)
+    if flat.shape[0]:
+        _lib.check(lib.pcl_cloud2idx_backward(_ptr(flat), _ptr(gflat), int(flat.shape[0]), _ptr(out), _stream()), "pcl_cloud2idx_backward")
+    return out.reshape(x.shape)
+
+
+def sample_from_img_backward(pano, coord, grad_rgb, want_coord=True, want_img=False):
+    """(grad_coord (.., 2) or None, grad_img (H, W, 3) or None) of sample_from_img for the incoming gradient grad_rgb (.., 3)."""
+    lib = _lib.load()
+    c, g = _dev(coord), _dev(grad_rgb)
+    flat, gflat = c.reshape(-1, 2), g.reshape(-1, 3)
+    if gflat.shape[0] != flat.shape[0]:
+        raise ValueError("grad_rgb must have one colour per coordinate")
+    gc = torch.empty_like(flat) if want_coord else None
+    gi = torch.zeros(pano.H, pano.W, 3, dtype=F32, device=c.device) if want_img else None
+    if flat.shape[0] and (want_coord or want_img):
+        _lib.check(lib.pcl_sample_from_img_backward(_ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(flat), _ptr(gflat), int(flat.shape[0]),
+                                                    _ptr(gc), _ptr(gi), _stream()), "pcl_sample_from_img_backward")
+    elif gc is not None:
+        gc.zero_()
+    return (gc.reshape(c.shape) if gc is not None else None), gi
+
+
 def rot_from_ypr(rot):
     lib = _lib.load()
     r = _dev(rot).reshape(-1, 3)

@@ -21,7 +21,7 @@ from .omniloc import packed_cloud, packed_pano
 
 __all__ = ["cloud2idx", "sample_from_img", "warp_from_img", "reshape_img_tensor", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
            "trim_input_hist_secondary", "make_input", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
-           "compute_sampling_grid", "create_coordinate", "write_summaries", "resize_image", "get_bound", "defaultdict", "torch", "np"]
+           "compute_sampling_grid", "create_coordinate", "write_summaries", "debug_visualize", "resize_image", "get_bound", "defaultdict", "torch", "np"]
 
 
 def _like(out, ref):
@@ -30,19 +30,57 @@ def _like(out, ref):
 
 
 # ------------------------------------------------------------------------------------------------ geometry ops
+class _Cloud2Idx(torch.autograd.Function):
+    """cloud2idx as an autograd op: forward and backward are one HIP kernel each (csrc/pcl_ops.hip)."""
+
+    @staticmethod
+    def forward(ctx, xyz):
+        ctx.save_for_backward(xyz)
+        return _like(ops.cloud2idx(xyz), xyz)
+
+    @staticmethod
+    def backward(ctx, grad_coord):
+        xyz, = ctx.saved_tensors
+        return _like(ops.cloud2idx_backward(xyz, grad_coord), xyz).to(xyz.dtype)
+
+
+class _SampleFromImg(torch.autograd.Function):
+    """sample_from_img as an autograd op: gradient w.r.t. the coordinates and, if asked for, the image."""
+
+    @staticmethod
+    def forward(ctx, img, coord_arr):
+        pano = packed_pano(img)
+        ctx.pano = pano
+        ctx.save_for_backward(img, coord_arr)
+        return _like(ops.sample_from_img(pano, coord_arr), coord_arr)
+
+    @staticmethod
+    def backward(ctx, grad_rgb):
+        img, coord = ctx.saved_tensors
+        want_img, want_coord = ctx.needs_input_grad
+        gc, gi = ops.sample_from_img_backward(ctx.pano, coord, grad_rgb, want_coord=want_coord, want_img=want_img)
+        return (_like(gi, img).to(img.dtype) if want_img else None), (_like(gc, coord).to(coord.dtype) if want_coord else None)
+
+
 def cloud2idx(xyz, batched=False):
     """(N,3) or (B,N,3) camera-frame points -> equirectangular coordinates in [-1,1]^2 (x = column, y = row).
-    Not differentiable here: the differentiable path is SamplingLoss (loss and gradient fused)."""
+    Differentiable like the reference's (a plain autograd op there, utils.py:16-61): if xyz requires grad the result
+    carries a grad_fn whose backward is the HIP kernel pcl_cloud2idx_backward."""
+    if torch.is_tensor(xyz) and xyz.requires_grad and torch.is_grad_enabled():
+        return _Cloud2Idx.apply(xyz)
     return _like(ops.cloud2idx(xyz), xyz)
 
 
 def sample_from_img(img, coord_arr, padding="zeros", mode="bilinear", batched=False):
-    """Bilinear lookup of (N,2) / (B,N,2) coordinates in an (H,W,3) image, clipped to +-0.99, zero padding."""
+    """Bilinear lookup of (N,2) / (B,N,2) coordinates in an (H,W,3) image, clipped to +-0.99, zero padding.
+    Differentiable w.r.t. the coordinates and the image like the reference's (torch.clip + F.grid_sample, utils.py:64-103)."""
     if padding != "zeros" or mode != "bilinear":
         raise NotImplementedError("sample_from_img: only padding='zeros', mode='bilinear' (all the reference uses)")
     if batched and coord_arr.shape[0] == 1:
         # the reference's batched path squeezes the batch away for B == 1 (utils.py:88) and then fails
         raise RuntimeError("sample_from_img(batched=True) needs B > 1, like the reference")
+    if torch.is_grad_enabled() and ((torch.is_tensor(coord_arr) and coord_arr.requires_grad) or (torch.is_tensor(img) and img.requires_grad)):
+        return _SampleFromImg.apply(img, coord_arr)
     return _like(ops.sample_from_img(packed_pano(img), coord_arr), coord_arr)
 
 
@@ -265,6 +303,38 @@ def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", 
         raise UnboundLocalError("make_input: only criterion='loss_histogram' is implemented (as in the reference)")
     t1, r1 = trim_input_loss(img, xyz, rgb, trans, rot, num_intermediate)
     return trim_input_hist_secondary(img, xyz, rgb, t1, r1, num_input, init_dict["num_split_h"], init_dict["num_split_w"])
+
+
+def debug_visualize(tgt_tensor):
+    """utils.py:641-699: show a tensor / array of shape (H,W), (H,W,C) or (B,H,W,C) with matplotlib (first batch item;
+    3 channels as RGB, otherwise one grey panel per channel; values above 2 are taken as 0..255).  Host-side helper kept for
+    the `from utils import *` surface.  (The reference's numpy branch uses `np.float`, removed in numpy 1.24.)"""
+    import matplotlib.pyplot as plt
+    if torch.is_tensor(tgt_tensor):
+        vis_tgt = tgt_tensor.detach().cpu().float().numpy()
+    elif isinstance(tgt_tensor, np.ndarray):
+        vis_tgt = tgt_tensor.astype(np.float64)
+    else:
+        raise ValueError("Invalid input!")
+    if vis_tgt.max() > 2.0:
+        vis_tgt = vis_tgt / 255.
+    if vis_tgt.ndim == 4:
+        vis_tgt = vis_tgt[0]
+    if vis_tgt.ndim == 2:
+        vis_tgt = vis_tgt[..., None]
+    if vis_tgt.ndim != 3:
+        return
+    C = vis_tgt.shape[2]
+    if C == 3:
+        plt.imshow(vis_tgt)
+    elif C == 1:
+        plt.imshow(vis_tgt[..., 0], cmap="gray", vmin=vis_tgt.min(), vmax=vis_tgt.max())
+    else:
+        fig = plt.figure(figsize=(50, 50))
+        for i in range(C):
+            fig.add_subplot(max(C // 2, 1), 2, i + 1)
+            plt.imshow(vis_tgt[..., i], cmap="gray", vmin=vis_tgt[..., i].min(), vmax=vis_tgt[..., i].max())
+    plt.show()
 
 
 def write_summaries(writer, scalar_summaries, step):

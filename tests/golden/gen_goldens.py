@@ -703,11 +703,50 @@ def g19_trim_hist_empty_blocks():
          ranked_trans=sel_t.numpy(), ranked_rot=sel_r.numpy(), num_split=np.array([nh, nw]))
 
 
+# ----------------------------------------------------------------------------- G20
+def g20_standalone_backward():
+    """Autograd of the reference's stand-alone utils.cloud2idx / utils.sample_from_img (fp32 and fp64): gradients w.r.t. the
+    points, the coordinates and the image, for random incoming gradients.  Inputs include the G1 special points (axes,
+    rho = 0, the wrap seam), coordinates beyond +-0.99 (clip) and footprints that touch the zero padding."""
+    g1 = np.load(os.path.join(HERE, "g1_cloud2idx.npz"))
+    xyz = g1["xyz"].astype(np.float32)
+    rng = np.random.default_rng(20)
+    G = rng.normal(size=(len(xyz), 2)).astype(np.float32)
+    out = {"xyz": xyz, "grad_coord_in": G}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        x = torch.from_numpy(xyz).to(dt).requires_grad_()
+        ref_utils.cloud2idx(x).backward(torch.from_numpy(G).to(dt))
+        out["grad_xyz_" + tag] = x.grad.numpy()
+        xb = torch.from_numpy(xyz[:900].reshape(3, 300, 3)).to(dt).requires_grad_()
+        ref_utils.cloud2idx(xb, batched=True).backward(torch.from_numpy(G[:900].reshape(3, 300, 2)).to(dt))
+        out["grad_xyz_b_" + tag] = xb.grad.numpy()
+    g2 = np.load(os.path.join(HERE, "g2_sample_from_img.npz"))
+    img, coord = g2["img"].astype(np.float32), g2["coord"].astype(np.float32)
+    Go = rng.normal(size=(len(coord), 3)).astype(np.float32)
+    out.update(img=img, coord=coord, grad_rgb_in=Go)
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        I = torch.from_numpy(img).to(dt).requires_grad_()
+        c = torch.from_numpy(coord).to(dt).requires_grad_()
+        ref_utils.sample_from_img(I, c).backward(torch.from_numpy(Go).to(dt))
+        out["grad_coord_" + tag] = c.grad.numpy()
+        out["grad_img_" + tag] = I.grad.numpy()
+    # composed, the way a caller would chain them: points -> cloud2idx -> sample_from_img -> sum of squares
+    pts = synth.box_room(2000, seed=20)[0]
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        p = torch.from_numpy(pts).to(dt).requires_grad_()
+        col = ref_utils.sample_from_img(torch.from_numpy(img).to(dt), ref_utils.cloud2idx(p))
+        (col ** 2).sum().backward()
+        out["chain_grad_" + tag] = p.grad.numpy()
+    out["chain_pts"] = pts
+    save("g20_standalone_backward.npz", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
             g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils,
-            g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks]
+            g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks,
+            g20_standalone_backward]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

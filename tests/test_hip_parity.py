@@ -369,6 +369,95 @@ def test_sampling_loss_function_surface(ops, parity):
     assert float(cpu) == losses[1]
 
 
+def test_standalone_ops_are_differentiable_like_the_reference(ops, oracle, parity):
+    """G20: utils.cloud2idx / utils.sample_from_img used as autograd ops (the reference's are plain torch code, utils.py:16-103):
+    gradients w.r.t. the points, the coordinates and the image from the HIP backward kernels against the reference's
+    fp64 autograd, next to the reference's own fp32 gap; then the two chained, the way a caller would compose them."""
+    from piccolo_amd import utils
+    from test_oracle_golden import g20_regular
+    g = load_golden("g20_standalone_backward.npz")
+    ok = g20_regular(g)
+    x = T(g["xyz"]).requires_grad_()
+    out = utils.cloud2idx(x)
+    assert out.requires_grad and np.abs(out.detach().cpu().numpy() - load_golden("g1_cloud2idx.npz")["coord"]).max() <= 5e-7
+    out.backward(T(g["grad_coord_in"]))
+    ref = g["grad_xyz_f64"]
+    scale = np.maximum(np.abs(ref), 1.0)
+    gap = (np.abs(g["grad_xyz_f32"] - ref) / scale)[ok].max()
+    parity("cloud2idx: grad_xyz vs ref fp64 (regular points)", (np.abs(x.grad.cpu().numpy() - ref) / scale)[ok].max(), 2 * gap + 1e-6, gap)
+    assert torch.isfinite(x.grad[torch.from_numpy(ok).cuda()]).all()
+    xb = T(g["xyz"][:900].reshape(3, 300, 3)).requires_grad_()
+    utils.cloud2idx(xb, batched=True).backward(T(g["grad_coord_in"][:900].reshape(3, 300, 2)))
+    okb = ok[:900].reshape(3, 300)
+    refb = g["grad_xyz_b_f64"]
+    parity("cloud2idx batched: grad_xyz vs ref fp64", (np.abs(xb.grad.cpu().numpy() - refb) / np.maximum(np.abs(refb), 1.0))[okb].max(), 2 * gap + 1e-6, gap)
+    # sample_from_img: coordinates and image, all three texel formats (the golden image is k/255)
+    for fmt in ("auto", "f32"):
+        from piccolo_amd import omniloc as po
+        po._cache.clear()
+        import os
+        os.environ["PCL_PANO_FMT"] = "f32" if fmt == "f32" else "f16"
+        try:
+            img, c = T(g["img"]).requires_grad_(), T(g["coord"]).requires_grad_()
+            col = utils.sample_from_img(img, c)
+            assert col.requires_grad
+            col.backward(T(g["grad_rgb_in"]))
+        finally:
+            os.environ.pop("PCL_PANO_FMT", None)
+        gap_c = np.abs(g["grad_coord_f32"] - g["grad_coord_f64"]).max()
+        gap_i = np.abs(g["grad_img_f32"] - g["grad_img_f64"]).max()
+        # (coordinates stored as float32(0.99) sit inside the fp32 clip range and outside the fp64 one: they are compared
+        # with the reference's fp32 run only)
+        edge = (np.abs(np.abs(g["coord"]) - np.float32(0.99)) < 1e-6).any(1)
+        gap_c = np.abs(g["grad_coord_f32"] - g["grad_coord_f64"])[~edge].max()
+        parity("sample_from_img[%s]: grad_coord vs ref fp64 (abs, values up to 50)" % fmt,
+               np.abs(c.grad.cpu().numpy() - g["grad_coord_f64"])[~edge].max(), 2 * gap_c + 1e-5, gap_c)
+        parity("sample_from_img[%s]: grad_coord vs ref fp32 (abs, all points)" % fmt,
+               np.abs(c.grad.cpu().numpy() - g["grad_coord_f32"]).max(), 2 * gap_c + 1e-5)
+        parity("sample_from_img[%s]: grad_img vs ref fp64 (abs)" % fmt, np.abs(img.grad.cpu().numpy() - g["grad_img_f64"]).max(), 2 * gap_i + 1e-5, gap_i)
+        # clip: exactly no gradient outside [-0.99, 0.99] (pattern of the reference's fp32 run: a coordinate stored as
+        # float32(0.99) is inside the fp32 clip range and outside the fp64 one)
+        assert np.array_equal(c.grad.cpu().numpy() == 0, g["grad_coord_f32"] == 0)
+    # only the coordinates need a gradient: no image gradient is produced
+    c = T(g["coord"]).requires_grad_()
+    im = T(g["img"])
+    utils.sample_from_img(im, c).sum().backward()
+    assert im.grad is None and c.grad is not None
+    # chained: points -> cloud2idx -> sample_from_img -> sum of squares
+    p = T(g["chain_pts"]).requires_grad_()
+    (utils.sample_from_img(T(g["img"]), utils.cloud2idx(p)) ** 2).sum().backward()
+    refc = g["chain_grad_f64"]
+    gapc = np.abs(g["chain_grad_f32"] - refc).max() / np.abs(refc).max()
+    parity("cloud2idx -> sample_from_img chain: grad_points vs ref fp64", np.abs(p.grad.cpu().numpy() - refc).max() / np.abs(refc).max(), 2 * gapc + 1e-6, gapc)
+    # without requires_grad nothing is recorded (the fast path of the harness)
+    assert not utils.cloud2idx(T(g["xyz"])).requires_grad
+
+
+def test_omniloc_visualize_frames(ops):
+    """cfg.visualize: a 4th return value with the frame list the reference's code means to build (omniloc.py:59-69,93-100):
+    num_iter frames + 4 repeats of the first + 10 of the last + 5 closing frames, each the query image over the current
+    render at half resolution; the pose result is bit-identical to the run without frames (same launches, one by one)."""
+    from PIL import Image
+    from piccolo_amd import omniloc as po
+    g = load_golden("g5_trajectories.npz")
+    d = json.loads(str(g["cfg"]))
+    d["num_iter"] = 12
+    img, xyz, rgb = T(g["img"]), T(g["xyz"]), T(g["rgb"])
+    plain = po.omniloc(img, xyz, rgb, T(g["trans0"].copy()), T(g["rot0"].copy()), 0, Cfg(**d), {})
+    res = po.omniloc(img, xyz, rgb, T(g["trans0"].copy()), T(g["rot0"].copy()), 0, Cfg(**dict(d, visualize=True)), {})
+    assert len(res) == 4 and all(torch.equal(a, b) for a, b in zip(plain, res[:3]))
+    frames = res[3]
+    H, W = g["img"].shape[:2]
+    assert len(frames) == 12 + 4 + 10 + 5
+    assert all(isinstance(f, Image.Image) and f.size == (W // 2, 2 * (H // 2)) for f in frames)
+    assert frames[0] is frames[4] and frames[-6] is frames[-15]
+    top = np.asarray(frames[3])[: H // 2]
+    low_first, low_last, low_closing = np.asarray(frames[0])[H // 2:], np.asarray(frames[-6])[H // 2:], np.asarray(frames[-1])[H // 2:]
+    assert top.any() and low_first.any() and (low_closing == 0).all()
+    assert (low_first != low_last).any()                    # the render follows the pose
+    np.asarray([res], dtype=object)                         # localize.py:227 / :285 index this as result[:, 3][min_ind]
+
+
 def test_modules_autograd(ops, parity):
     """SamplingLoss / BatchSamplingLoss are differentiable modules: .backward() fills the pose leaves' .grad with the
     gradients of G3/G4."""

@@ -56,3 +56,21 @@ def test_sub_keys_versions_and_dead_tensors():
     shapes = [k[1][1] for k in po._cache.kinds["box"]]
     assert (5, 3) not in shapes and (7, 3) in shapes
     assert len(po._cache.kinds["box"]) <= po._CAPACITY["box"]
+
+
+def test_debug_visualize_host_helper(monkeypatch):
+    """utils.debug_visualize (utils.py:641-699): accepts (H,W), (H,W,C), (B,H,W,C) tensors / arrays, rejects anything else."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    import numpy as np
+    import pytest
+    from piccolo_amd import utils
+    shown = []
+    monkeypatch.setattr(plt, "show", lambda *a, **k: shown.append(len(plt.gcf().axes)))
+    for t in (torch.rand(8, 16), torch.rand(8, 16, 3), torch.rand(8, 16, 1), torch.rand(2, 8, 16, 4), np.random.rand(8, 16, 2) * 255):
+        utils.debug_visualize(t)
+        plt.close("all")
+    assert shown == [1, 1, 1, 4, 2]
+    with pytest.raises(ValueError):
+        utils.debug_visualize([1, 2, 3])
