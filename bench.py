@@ -177,8 +177,15 @@ def main():
     # Images are refined in groups of `ipl`: the group's ipl * B candidates go through ONE chain of launches (shared
     # cloud, per-candidate panorama pointer).  More poses per launch share each cloud chunk in L2 and amortise the
     # per-block costs; the candidates stay independent (own Adam / scheduler state), so per-image results are the same.
-    ipl = args.images_per_launch if args.images_per_launch > 0 else max(1, 256 // B)
-    ipl = max(1, min(ipl, K))
+    if args.images_per_launch > 0:
+        ipl = max(1, min(args.images_per_launch, K))
+    else:
+        # auto: about 256 poses per launch, in EQUAL groups when the step count allows it (every timed launch then has
+        # one shape, the one the counter passes under profiles/ were taken for): the largest divisor of K that is at most
+        # 256 // B and at least half of it; otherwise groups of 256 // B with a shorter last one
+        target = max(1, min(256 // B, K))
+        divs = [d for d in range(target, 0, -1) if K % d == 0 and 2 * d >= target]
+        ipl = divs[0] if divs else target
     # warm-up steps refine their OWN images (ids beyond every rank's timed ones), in whole launch groups of the timed size
     n_warm = ((Wm + ipl - 1) // ipl) * ipl if Wm > 0 else 0
     n_img = K + n_warm

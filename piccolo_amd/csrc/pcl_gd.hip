@@ -3,8 +3,8 @@
 // Replaces, per GD iteration of the reference: the tail of autograd (omniloc.py:47,254), B x Adam.step and
 // B x ReduceLROnPlateau.step(float(loss)) — each a host sync — (omniloc.py:49-50, :256-258), the re-cat of the
 // parameters (omniloc.py:260-263) and the clamp to the quantile box (omniloc.py:52-58, :265-269).
-// One 64-lane block per candidate pose; lane 0 runs the scalar optimiser update in the same precision mix as
-// the reference (fp32 tensors, python-double scalars).
+// One 256-thread block per candidate pose (four waves gather the partial sums, wave 0 runs the optimiser update in the
+// same precision mix as the reference: fp32 tensors, python-double scalars).
 #include "pcl_gd_device.h"
 
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
@@ -25,15 +25,20 @@ __global__ void pcl_pose_setup_kernel(const float* __restrict__ trans, const flo
     pcl_write_pose_rec(&recs[b], p);
 }
 
-__global__ void __launch_bounds__(PCL_WAVE) pcl_finish_kernel(const float* __restrict__ partials, int nchunks, int B,
-                                                              const PclPoseRec* __restrict__ recs,
-                                                              const float* __restrict__ rot, int with_grad,
-                                                              float* __restrict__ result)
+__global__ void __launch_bounds__(PCL_GD_THREADS) pcl_finish_kernel(const float* __restrict__ partials, int nchunks, int B,
+                                                                    const PclPoseRec* __restrict__ recs,
+                                                                    const float* __restrict__ rot, int with_grad,
+                                                                    float* __restrict__ result)
 {
     int b = blockIdx.x;
+    __shared__ double red[PCL_GD_THREADS / PCL_WAVE][PCL_NACC];
     double s[PCL_NACC];
-    pcl_reduce_partials(partials, nchunks, B, b, threadIdx.x, s);
+    pcl_reduce_partials(partials, nchunks, B, b, threadIdx.x, PCL_GD_THREADS, s);
+    if ((threadIdx.x & 63) == 0)
+        for (int q = 0; q < PCL_NACC; q++) red[threadIdx.x >> 6][q] = s[q];
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int q = 0; q < PCL_NACC; q++) s[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
         float loss, g[6] = {0, 0, 0, 0, 0, 0};
         if (with_grad) {
             double sy, cy, sp, cp;
@@ -66,7 +71,7 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano
     PCL_LAUNCH_CHECK();
     int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
+    hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
                        with_grad, result);
     PCL_LAUNCH_CHECK();
     return 0;
@@ -95,10 +100,10 @@ __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float*
     st[b] = g;
 }
 
-__global__ void __launch_bounds__(PCL_WAVE) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks, int B,
-                                                                   PclGdPose* st, PclPoseRec* recs,
-                                                                   const float* __restrict__ box, double factor,
-                                                                   int patience, int mode, float* loss_out)
+__global__ void __launch_bounds__(PCL_GD_THREADS) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks, int B,
+                                                                         PclGdPose* st, PclPoseRec* recs,
+                                                                         const float* __restrict__ box, double factor,
+                                                                         int patience, int mode, float* loss_out)
 {
     pcl_gd_finish_pose(partials, nchunks, B, blockIdx.x, threadIdx.x, st, recs, box, factor, patience, mode, loss_out);
 }
@@ -226,7 +231,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             if (e != hipSuccess) return (int)e;
             tm->used++;
         }
-        hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_WAVE), 0, s, partials, nchunks, B, gd_poses(state),
+        hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, B, gd_poses(state),
                            gd_recs(state, B), box, hyper_host->factor, (int)hyper_host->patience, (int)hyper_host->mode,
                            loss_history ? loss_history + (int64_t)it * B : nullptr);
         PCL_LAUNCH_CHECK();

@@ -9,17 +9,25 @@
 #pragma once
 #include "pcl_device.h"
 
-// Deterministic second-stage sum of the per-chunk partials of pose `b` (fixed lane->chunk assignment, double).
-__device__ __forceinline__ void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, int lane, double out[PCL_NACC])
+// Deterministic second-stage sum of the per-chunk partials of pose `b` over one WAVE's share of the chunks: thread `tid`
+// of `nthreads` takes chunks tid, tid + nthreads, ... (fixed assignment, double), then the wave's lanes are summed.
+// Two rows per trip so that a thread's loads are in flight together.
+__device__ __forceinline__ void pcl_reduce_partials(const float* __restrict__ partials, int nchunks, int B, int b, int tid, int nthreads,
+                                                    double out[PCL_NACC])
 {
     double s[PCL_NACC];
 #pragma unroll
     for (int k = 0; k < PCL_NACC; k++) s[k] = 0.0;
-    for (int c = lane; c < nchunks; c += PCL_WAVE) {
+    for (int c = tid; c < nchunks; c += 2 * nthreads) {
+        const int c2 = c + nthreads;
         const pcl_f4* p = reinterpret_cast<const pcl_f4*>(partials + ((int64_t)c * B + b) * PCL_NACC);
-        pcl_f4 lo = p[0], hi = p[1];
+        const pcl_f4* q = reinterpret_cast<const pcl_f4*>(partials + ((int64_t)(c2 < nchunks ? c2 : c) * B + b) * PCL_NACC);
+        pcl_f4 lo = p[0], hi = p[1], lo2 = q[0], hi2 = q[1];
+        if (c2 >= nchunks) { lo2 = (pcl_f4){0.f, 0.f, 0.f, 0.f}; hi2 = lo2; }
         s[0] += lo.x; s[1] += lo.y; s[2] += lo.z; s[3] += lo.w;
         s[4] += hi.x; s[5] += hi.y; s[6] += hi.z; s[7] += hi.w;
+        s[0] += lo2.x; s[1] += lo2.y; s[2] += lo2.z; s[3] += lo2.w;
+        s[4] += hi2.x; s[5] += hi2.y; s[6] += hi2.z; s[7] += hi2.w;
     }
 #pragma unroll
     for (int k = 0; k < PCL_NACC; k++) out[k] = pcl_wave_sum_d(s[k]);
@@ -41,31 +49,59 @@ __device__ __forceinline__ void pcl_chain_rule(const double s[PCL_NACC], const f
     grad[5] = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
 }
 
-// One wave (`lane` = 0..63) finishes pose b: deterministic reduction, chain rule, Adam, plateau scheduler, clamp, next
-// pose record.  The per-parameter work runs lane-parallel — lane k < 6 owns parameter k (t0, t1, t2, yaw, pitch, roll):
-// its gradient component, its Adam update, its clamp; lanes 3..5 take the sin/cos of the three angles at once — because
-// a single lane walking through six updates and three sincosf was a 5 us dependent instruction chain per iteration.
-// Every element goes through exactly the operations it went through in the one-lane form (bit-identical results).
-__device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ partials, int nchunks, int B, int b, int lane, PclGdPose* st,
+// One 256-thread block finishes pose b: deterministic reduction, chain rule, Adam, plateau scheduler, clamp, next pose
+// record.  An iteration of a small problem is two dependent launches of a few microseconds each, so this kernel is all
+// latency (rocprofv3, round 2: 5.3 us of a 15 us iteration at the shipped 167k-point / 6-candidate shape):
+//   - everything the update needs (optimiser state, pose record, clamp box) is requested BEFORE the partial sums, so
+//     that one memory round trip covers both;
+//   - the per-chunk partials are spread over four waves (one or two rows per thread: a single round of loads instead
+//     of a loop of dependent ones per lane), wave sums by DPP, the four wave results through LDS;
+//   - the per-parameter work then runs lane-parallel in wave 0 — lane k < 6 owns parameter k (t0, t1, t2, yaw, pitch,
+//     roll): its gradient component, its Adam update, its clamp; lanes 3..5 take the sin/cos of the three angles at once.
+// Every element goes through exactly the operations of the scalar form; the order of the fixed-order double sums is part
+// of the build (same for eager launches, graph replay and the stateless pcl_finish_kernel).
+#define PCL_GD_THREADS 256
+__device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ partials, int nchunks, int B, int b, int tid, PclGdPose* st,
                                           PclPoseRec* recs, const float* __restrict__ box, double factor, int patience, int mode,
                                           float* loss_out)
 {
     // torch evaluates the optimiser with separate, individually rounded tensor operations: no fused multiply-adds here
 #pragma clang fp contract(off)
-    double s[PCL_NACC];
-    pcl_reduce_partials(partials, nchunks, B, b, lane, s);      // every lane holds the eight sums
     PclGdPose* gp = st + b;
     PclPoseRec* rec = recs + b;
-    const bool owner = lane < 6;
-    const int k = owner ? lane : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool owner = tid < 6;
+    const int k = owner ? tid : 0;
+    // ---- requests first (independent of the sums)
+    const float sc0 = gp->sc[0], sc1 = gp->sc[1], sc2 = gp->sc[2], sc3 = gp->sc[3];
+    const float Rk0 = rec->R[k < 3 ? k : 0], Rk1 = rec->R[3 + (k < 3 ? k : 0)], Rk2 = rec->R[6 + (k < 3 ? k : 0)];
+    double lr = gp->lr, best = gp->best;
+    int num_bad = gp->num_bad;
+    const int step = gp->step + 1;
+    const double beta1_pow_in = gp->beta1_pow, beta2_pow_in = gp->beta2_pow;
+    float m = gp->m[k], v = gp->v[k], leaf = gp->leaf[k];
+    const float box_lo = box[2 * (k < 3 ? k : 0)], box_hi = box[2 * (k < 3 ? k : 0) + 1];
+
+    // ---- second-stage sums of the per-chunk partials (fixed thread -> chunk assignment, double)
+    __shared__ double red[PCL_GD_THREADS / PCL_WAVE][PCL_NACC];
+    double s[PCL_NACC];
+    pcl_reduce_partials(partials, nchunks, B, b, tid, PCL_GD_THREADS, s);      // every lane holds its WAVE's eight sums
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < PCL_NACC; q++) red[wave][q] = s[q];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int q = 0; q < PCL_NACC; q++) s[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
 
     // loss and this lane's gradient component (pcl_chain_rule, one component per lane)
     const double M = s[1];
     const float loss = (float)s[0] / (float)M;
     const double inv = 1.0 / M;
-    const double sy = gp->sc[0], cy = gp->sc[1], sp = gp->sc[2], cp = gp->sc[3];
+    const double sy = sc0, cy = sc1, sp = sc2, cp = sc3;
     float gk;
-    if (k < 3) gk = (float)(-((double)rec->R[k] * s[2] + (double)rec->R[3 + k] * s[3] + (double)rec->R[6 + k] * s[4]) * inv);
+    if (k < 3) gk = (float)(-((double)Rk0 * s[2] + (double)Rk1 * s[3] + (double)Rk2 * s[4]) * inv);
     else if (k == 3) gk = (float)(s[7] * inv);
     else if (k == 4) gk = (float)((-sy * s[5] + cy * s[6]) * inv);
     else gk = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
@@ -73,17 +109,13 @@ __device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ par
     // torch.optim.Adam, single-tensor form (betas 0.9/0.999, eps 1e-8; call sites omniloc.py:33,235-236):
     // fp32 tensor math, python-double scalars
     const double beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
-    double lr = gp->lr, best = gp->best;
-    int num_bad = gp->num_bad;
-    const int step = gp->step + 1;
-    const double beta1_pow = gp->beta1_pow * beta1;             // beta ** step as a running product (python: pow)
-    const double beta2_pow = gp->beta2_pow * beta2;
+    const double beta1_pow = beta1_pow_in * beta1;              // beta ** step as a running product (python: pow)
+    const double beta2_pow = beta2_pow_in * beta2;
     const double bc1 = 1.0 - beta1_pow;
     const double bc2 = 1.0 - beta2_pow;
     const float step_size = (float)(-(lr / bc1));
     const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
-    float m = gp->m[k], v = gp->v[k], leaf = gp->leaf[k];
     m = m + w1 * (gk - m);                                      // exp_avg.lerp_(grad, 1 - beta1)
     v = v * b2 + w2 * gk * gk;                                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(v) / bc2_sqrt + (float)eps;       // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
@@ -104,7 +136,7 @@ __device__ __forceinline__ void pcl_gd_finish_pose(const float* __restrict__ par
     // clamp t to the quantile box; batch mode forwards the pre-clamp copy (omniloc.py:260-269), sequential mode
     // clamps the very tensor the next forward reads (omniloc.py:56-58)
     float fwd = leaf;
-    if (k < 3) leaf = fminf(fmaxf(leaf, box[2 * k]), box[2 * k + 1]);
+    if (k < 3) leaf = fminf(fmaxf(leaf, box_lo), box_hi);
     if (mode != PCL_GD_BATCH) fwd = leaf;
 
     // next pose record: lanes 3..5 hold yaw, pitch, roll (same fp32 sincosf + double products as pcl_write_pose_rec_fast)

@@ -18,6 +18,7 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     omniloc returns the frame list that code means to build (query image over the cloud rendered at the current pose,
     per iteration) as 4th element.
 """
+import os
 import weakref
 from collections import OrderedDict
 
@@ -34,7 +35,7 @@ strict_reference_asserts = True
 # cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
 # An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
 # references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
-_CAPACITY = {"cloud": 2, "order": 2, "box": 4, "grid": 4, "pano": 16, "pano_u8": 4}
+_CAPACITY = {"cloud": 2, "order": 2, "box": 4, "grid": 4, "pano": 16, "pano_u8": 4, "gd": 6}
 
 
 class _PackCache:
@@ -133,6 +134,54 @@ def _rot_matrix(ypr):
 
 
 # ------------------------------------------------------------------------------------------------ GD drivers
+# A refinement of a SMALL problem is launch-latency bound: 2 x num_iter dependent launches of a few microseconds each
+# (the reference's shipped configs: 167k points x 6 candidates, 15 us per iteration on the GPU).  For those the whole
+# launch chain is captured once into a hipGraph and replayed for every later refinement of the same cloud and shape —
+# pcl_gd_run neither allocates nor synchronises, every candidate reads its panorama through its pose record
+# (pcl_gd_set_panos), so a new image only needs pcl_gd_init + pcl_gd_set_panos + one graph launch.  Replay is
+# bit-identical to the eager launches (tests).  Measured at cfg 1: 0.65 vs 0.73 ms per refinement; nothing at cfg 2
+# (110 us kernels), hence the size limit.
+GRAPH_POINT_POSES = 4_000_000          # use graph replay when points x candidates is at most this (cfg key gd_graph overrides)
+
+
+def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
+    """Run the on-device GD for the rows of trans / rot (candidate b samples panos[b]) and return gd.result().
+    The GradientDescent object (state, workspace, captured graph) is cached per cloud and launch shape."""
+    cloud = packed_cloud(xyz, rgb)
+    trans, rot = ops._dev(trans).reshape(-1, 3), ops._dev(rot).reshape(-1, 3)
+    B = int(trans.shape[0])
+    p0 = panos[0]
+    num_iter = _cfg(cfg, "num_iter", 100)
+    depth = bool(_cfg(cfg, "depth_mask", False))
+    hyper = (float(_cfg(cfg, "lr", 0.1)), int(_cfg(cfg, "patience", 5)), float(_cfg(cfg, "factor", 0.9)), bool(batch_mode), depth,
+             float(_cfg(cfg, "depth_tau", 0.02)))
+    use_graph = _cfg(cfg, "gd_graph", None)
+    if use_graph is None and os.environ.get("PCL_GD_GRAPH") in ("0", "1"):          # experiments
+        use_graph = os.environ["PCL_GD_GRAPH"] == "1"
+    if use_graph is None:
+        use_graph = cloud.n * B <= GRAPH_POINT_POSES
+    use_graph = bool(use_graph) and vis_hook is None and not depth
+
+    def make():
+        return ops.GradientDescent(cloud, p0, trans, rot, box, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
+                                   depth_mask=hyper[4], depth_tau=hyper[5])
+    if not use_graph:
+        gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
+    else:
+        gd = _cached("gd", (xyz, rgb), make, sub=(B, p0.H, p0.W, p0.fmt) + hyper)
+        gd.box.copy_(ops._dev(box).reshape(6))              # in place: the captured graph holds this buffer's address
+        gd.reset(trans, rot)
+    if len(panos) > 1 or use_graph:
+        gd.set_panos(list(panos) if len(panos) == B else [p0] * B)
+    if vis_hook is not None:
+        vis_hook(gd, num_iter)
+    elif use_graph:
+        gd.run_graph(num_iter)
+    else:
+        gd.run(num_iter)
+    return gd.result()
+
+
 def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_summaries):
     """Sequential refinement of ONE starting pose.  Returns [t (3,1), R (3,3), loss ()] (+ frames if cfg.visualize).
 
@@ -140,25 +189,15 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     (omniloc.py:46,102).  Row `starting_point` of input_trans / input_rot ends up holding the final pose, as in the
     reference where the optimised tensors are views of those rows (omniloc.py:15-19).
     """
-    lr = _cfg(cfg, "lr", 0.1)
-    num_iter = _cfg(cfg, "num_iter", 100)
-    patience = _cfg(cfg, "patience", 5)
-    factor = _cfg(cfg, "factor", 0.9)
     vis = _cfg(cfg, "visualize", False)
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
 
-    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
+    pano = packed_pano(img)
     # the reference recomputes these three quantiles every iteration (omniloc.py:53-55); they are loop invariant
     box = quantile_box_of(xyz, out_quantile)
-    gd = ops.GradientDescent(cloud, pano, input_trans[starting_point], input_rot[starting_point], box,
-                             lr=lr, patience=patience, factor=factor, batch_mode=False,
-                             depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
-    frames = None
-    if vis:
-        frames = _run_with_frames(gd, img, xyz, rgb, num_iter)
-    else:
-        gd.run(num_iter)
-    res = gd.result()[0]
+    frames = []
+    hook = (lambda gd, n: frames.extend(_run_with_frames(gd, img, xyz, rgb, n))) if vis else None
+    res = _refine(xyz, rgb, [pano], input_trans[starting_point], input_rot[starting_point], box, cfg, False, vis_hook=hook)[0]
     R = _rot_matrix(res[3:6])
     out = torch.cat([res[0:3], R.reshape(-1), res[12:13]]).cpu()
     with torch.no_grad():
@@ -201,14 +240,8 @@ def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=Non
     `for i in range(num_input): omniloc(..., i, ...)` (localize.py:219-220), for ALL starting points in one launch chain.
     Every starting point keeps omniloc's SEQUENTIAL semantics (its own Adam / scheduler, clamp applied to the parameters
     the next forward reads) and the points never interact, so the list returned equals the K separate calls."""
-    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
-    out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
-    box = quantile_box_of(xyz, out_quantile)
-    gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
-                             factor=_cfg(cfg, "factor", 0.9), batch_mode=False, depth_mask=_cfg(cfg, "depth_mask", False),
-                             depth_tau=_cfg(cfg, "depth_tau", 0.02))
-    gd.run(_cfg(cfg, "num_iter", 100))
-    res = gd.result()
+    box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
+    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, False)
     K = res.shape[0]
     R = ops.rot_from_ypr(res[:, 3:6])
     host = torch.cat([res[:, 0:3], R.reshape(K, 9), res[:, 12:13]], dim=1).cpu()
@@ -224,18 +257,8 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     returned translation is the post-step, pre-clamp value (omniloc.py:272)."""
     if strict_reference_asserts:
         assert cfg.num_input > 1
-    lr = _cfg(cfg, "lr", 0.1)
-    num_iter = _cfg(cfg, "num_iter", 100)
-    patience = _cfg(cfg, "patience", 5)
-    factor = _cfg(cfg, "factor", 0.9)
-    out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
-
-    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
-    box = quantile_box_of(xyz, out_quantile)
-    gd = ops.GradientDescent(cloud, pano, input_trans, input_rot, box, lr=lr, patience=patience, factor=factor,
-                             batch_mode=True, depth_mask=_cfg(cfg, "depth_mask", False), depth_tau=_cfg(cfg, "depth_tau", 0.02))
-    gd.run(num_iter)
-    res = gd.result()                       # (B, 14) on the GPU
+    box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
+    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, True)      # (B, 14) on the GPU
     k = torch.argmin(res[:, 12])            # loss_list.argmin() of the last forward
     win = res[k]
     R = _rot_matrix(win[3:6])
@@ -259,20 +282,13 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
         assert cfg.num_input > 1
     I = len(imgs)
     B = int(input_trans_list[0].shape[0])
-    cloud = packed_cloud(xyz, rgb)
     panos = [packed_pano(im) if I <= 8 else ops.Pano(im) for im in imgs]
     if len({p.fmt for p in panos}) > 1:          # a launch needs ONE texel format: float4 holds any image
         panos = [ops.Pano(im, fmt="f32") for im in imgs]
-    out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
-    box = quantile_box_of(xyz, out_quantile)
+    box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
     tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])
     ro = torch.cat([ops._dev(r).reshape(B, 3) for r in input_rot_list])
-    gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=_cfg(cfg, "lr", 0.1), patience=_cfg(cfg, "patience", 5),
-                             factor=_cfg(cfg, "factor", 0.9), batch_mode=batch_mode, depth_mask=_cfg(cfg, "depth_mask", False),
-                             depth_tau=_cfg(cfg, "depth_tau", 0.02))
-    gd.set_panos([panos[i] for i in range(I) for _ in range(B)])
-    gd.run(_cfg(cfg, "num_iter", 100))
-    res = gd.result().reshape(I, B, -1)
+    res = _refine(xyz, rgb, [panos[i] for i in range(I) for _ in range(B)], tr, ro, box, cfg, batch_mode).reshape(I, B, -1)
     k = torch.argmin(res[:, :, 12], dim=1)
     win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]        # (I, 14)
     R = ops.rot_from_ypr(win[:, 3:6])                                                        # (I, 3, 3)

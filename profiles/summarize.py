@@ -3,10 +3,12 @@
 
   <dir>/kt/**/*kernel_stats.csv          -> summary/kernel_stats.txt   (per-kernel calls / total / average)
   <dir>/pmc*/**/*counter_collection.csv  -> summary/pmc.json           (per kernel: mean counter value per dispatch)
-  + summary/traffic.json: HBM bytes per launch of the loss kernel, corrected as MI355X_MICROARCH.md prescribes
-    (FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, i.e. it reports
-    half the bytes of a wide stream -> doubled; the pack kernels, whose byte counts are known, give the measured
-    calibration factor that is reported next to it).
+  + summary/kernel_roofs.json: per pcl_* kernel the memory-side bytes per launch, corrected as MI355X_MICROARCH.md
+    prescribes (FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, i.e. it
+    reports half the bytes of a wide stream -> doubled), L2 hit rate, VALU-busy fraction
+    (4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): SQ_* count quad-cycles) and the wave-cycle split
+  + summary/roofs.json (if ROOF_KEY is set): the loss kernel's entry under its launch-shape key, the format of
+    profiles/roofs.json that bench.py reads (ROOF_KEY = workload/posesN/texels, POINT_POSES = points x poses per launch).
 """
 import csv
 import glob
@@ -41,26 +43,41 @@ def main(d):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     summ = {k: {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()} for k, cs in pmc.items()}
     json.dump(summ, open(os.path.join(out, "pmc.json"), "w"), indent=1, sort_keys=True)
-    loss = [k for k in summ if k.startswith("pcl_loss_kernel")]
-    for k in loss:
-        c = summ[k]
-        print(k, {n: round(v["mean"], 1) for n, v in c.items()})
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            fetch, write = c["FETCH_SIZE"]["mean"] * 1024, c["WRITE_SIZE"]["mean"] * 1024
-            tr = {"kernel": k, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                  "hbm_bytes_per_launch": 2 * fetch + write,
-                  "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide reads); "
-                          "includes Infinity-Cache hits (memory-side request counters)"}
-            json.dump(tr, open(os.path.join(out, "traffic_%s.json" % k.replace("<", "_").replace(">", "").replace(", ", "_")), "w"), indent=1)
-            print("traffic", tr)
-            # bench.py reads profiles/traffic.json: {workload: {"hbm_bytes_per_launch": ...}}
-            wl = os.environ.get("WORKLOAD", "cfg2")
-            merged = {}
-            tj = os.path.join(out, "traffic.json")
-            if os.path.exists(tj):
-                merged = json.load(open(tj))
-            merged[wl] = tr
-            json.dump(merged, open(tj, "w"), indent=1)
+    # per kernel: memory-side traffic (FETCH_SIZE doubled, MI355X_MICROARCH.md) and the VALU roof
+    roofs, point_poses, key = {}, float(os.environ.get("POINT_POSES", "0") or 0), os.environ.get("ROOF_KEY", "")
+    for k, c in summ.items():
+        if not k.startswith("pcl_"):
+            continue
+        m = {n: v["mean"] for n, v in c.items()}
+        r = {"kernel": k, "dispatches_sampled": max(v["n"] for v in c.values())}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            fetch, write = m["FETCH_SIZE"] * 1024, m["WRITE_SIZE"] * 1024
+            r.update(fetch_size_bytes_raw=fetch, write_size_bytes=write, hbm_bytes_per_launch=2 * fetch + write,
+                     traffic_note="2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; gfx950 reports half the bytes of wide reads); "
+                                  "memory-side request counters, Infinity-Cache hits included")
+        if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+            r["valu_busy_frac"] = 4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * m["GRBM_GUI_ACTIVE"] / 8)
+        if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m and m["TCC_HIT_sum"] + m["TCC_MISS_sum"] > 0:
+            r["l2_hit_frac"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+        if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"] > 0:
+            for n in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
+                if n in m:
+                    r[n.lower() + "_per_wave_cycle"] = m[n] / m["SQ_WAVE_CYCLES"]
+        if "SQ_INSTS_VALU" in m:
+            r["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
+            if point_poses and k.startswith("pcl_loss_kernel") and "true" in k.split("<")[1].split(",")[1]:
+                r["valu_instr_per_point_pose"] = m["SQ_INSTS_VALU"] / (point_poses / 64.0)
+        roofs[k] = r
+        print(k, {n: (round(v, 4) if isinstance(v, float) else v) for n, v in r.items() if n not in ("traffic_note", "kernel")})
+    json.dump(roofs, open(os.path.join(out, "kernel_roofs.json"), "w"), indent=1, sort_keys=True)
+    if key:
+        # the GRAD variant of the loss kernel is the one bench.py's roofline is about
+        cand = [r for k, r in roofs.items() if k.startswith("pcl_loss_kernel") and ", true," in k]
+        if cand:
+            best = dict(max(cand, key=lambda r: r.get("valu_insts_per_launch", 0)))
+            best["source"] = "profiles/%s (rocprofv3 --pmc passes of: %s)" % (os.environ.get("ROOF_SOURCE", os.path.basename(d.rstrip("/"))), os.environ.get("ROOF_CMD", "bench.py"))
+            json.dump({key: best}, open(os.path.join(out, "roofs.json"), "w"), indent=1, sort_keys=True)
+            print("roofs.json:", key, {n: best.get(n) for n in ("hbm_bytes_per_launch", "valu_instr_per_point_pose", "valu_busy_frac")})
 
 
 if __name__ == "__main__":
