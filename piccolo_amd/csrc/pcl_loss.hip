@@ -80,10 +80,18 @@ __device__ __forceinline__ f2 pcl_atan_poly2(f2 t)
 }
 
 // first-octant angle atan(min/max) of two magnitudes (packed) and the "second is larger" flags
+// (the min as one VOP3 with |.| modifiers, in asm: for operands that come out of the rotation's asm block the compiler
+// cannot prove them canonical and would put a v_max x,x in front of every fminf)
+__device__ __forceinline__ float pcl_min_abs(float a, float b)
+{
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f2 pcl_atan_ratio2(float u0, float v0, float u1, float v1)
 {
-    f2 mn = {fminf(u0, v0), fminf(u1, v1)};
-    f2 rc = {__builtin_amdgcn_rcpf(fmaxf(fmaxf(u0, v0), 1e-37f)), __builtin_amdgcn_rcpf(fmaxf(fmaxf(u1, v1), 1e-37f))};
+    f2 mn = {pcl_min_abs(u0, v0), pcl_min_abs(u1, v1)};
+    f2 rc = {__builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(u0), fabsf(v0)), 1e-37f)), __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(u1), fabsf(v1)), 1e-37f))};
     return pcl_atan_poly2(mn * rc);
 }
 
@@ -93,7 +101,7 @@ __device__ __forceinline__ f2 pcl_atan2_2(f2 y, f2 x)
 {
     const float half_pi = 1.57079632679489661923f;
     float ax0 = fabsf(x.x), ax1 = fabsf(x.y), ay0 = fabsf(y.x), ay1 = fabsf(y.y);
-    f2 r = pcl_atan_ratio2(ax0, ay0, ax1, ay1);
+    f2 r = pcl_atan_ratio2(x.x, y.x, x.y, y.y);
     f2 alt = F2(half_pi) - r;
     r = (f2){ay0 > ax0 ? alt.x : r.x, ay1 > ax1 ? alt.y : r.y};
     f2 w = F2(half_pi) - r;
@@ -107,7 +115,7 @@ __device__ __forceinline__ f2 pcl_elevation2(f2 z, f2 rho)
 {
     const float half_pi = 1.57079632679489661923f;
     float az0 = fabsf(z.x), az1 = fabsf(z.y);
-    f2 r = pcl_atan_ratio2(rho.x, az0, rho.y, az1);
+    f2 r = pcl_atan_ratio2(rho.x, z.x, rho.y, z.y);
     f2 alt = F2(half_pi) - r;
     r = (f2){az0 > rho.x ? alt.x : r.x, az1 > rho.y ? alt.y : r.y};
     return (f2){copysignf(r.x, z.x), copysignf(r.y, z.y)};
@@ -201,7 +209,7 @@ struct PclProj {
     f2 px, py, pz;        // camera-frame point
     f2 rho2, rinv;        // px^2 + py^2 and 1/rho
     f2 fx, fy;            // bilinear fractions
-    f2 mphi, mth;         // dix/dphi, diy/dtheta, zeroed where the +-0.99 clip is active (clamp backward)
+    bool in_phi0, in_phi1, in_th0, in_th1;   // the +-0.99 clip is inactive (clamp backward passes the gradient only there)
     PclTaps<FMT> ta, tb;  // gathers in flight (point .x, point .y)
 };
 
@@ -211,10 +219,32 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
                                              __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
 {
     // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
-    f2 qx = x - F2(t[0]), qy = y - F2(t[1]), qz = z - F2(t[2]);
-    o.px = pcl_fma2(F2(R[2]), qz, pcl_fma2(F2(R[1]), qy, F2(R[0]) * qx));
-    o.py = pcl_fma2(F2(R[5]), qz, pcl_fma2(F2(R[4]), qy, F2(R[3]) * qx));
-    o.pz = pcl_fma2(F2(R[8]), qz, pcl_fma2(F2(R[7]), qy, F2(R[6]) * qx));
+    // The pose is six 64-bit SGPR pairs (R0,R1)(R2,R3)(R4,R5)(R6,R7)(R8,t0)(t1,t2) and every scalar is broadcast to both
+    // points by op_sel — written as ONE asm block: from the C expression F2(R[k]) the compiler copies each scalar into a
+    // pair of its own (s_mov x2), 24 SGPRs per pose that it then spills to VGPR lanes and reads back with v_readlane
+    // inside the loop.  Dependent packed-fp32 ops need one instruction between them (the compiler puts s_nop there):
+    // the three rows are interleaved, so every result is used three slots later; same operations in the same order.
+    {
+        const f2* __restrict__ P = reinterpret_cast<const f2*>(R);
+        const f2 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5];
+        f2 qx, qy, qz, px, py, pz;
+        asm("v_pk_add_f32 %3, %6, %13 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // qx = x - t0   (hi of p4)
+            "v_pk_add_f32 %4, %7, %14 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"                  // qy = y - t1   (lo of p5)
+            "v_pk_add_f32 %5, %8, %14 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // qz = z - t2   (hi of p5)
+            "v_pk_mul_f32 %0, %3, %9 op_sel_hi:[1,0]\n\t"                                            // px = qx R0
+            "v_pk_mul_f32 %1, %3, %10 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                              // py = qx R3
+            "v_pk_mul_f32 %2, %3, %12 op_sel_hi:[1,0]\n\t"                                           // pz = qx R6
+            "v_pk_fma_f32 %0, %9, %4, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                       // px += R1 qy
+            "v_pk_fma_f32 %1, %11, %4, %1 op_sel_hi:[0,1,1]\n\t"                                     // py += R4 qy
+            "v_pk_fma_f32 %2, %12, %4, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                      // pz += R7 qy
+            "v_pk_fma_f32 %0, %10, %5, %0 op_sel_hi:[0,1,1]\n\t"                                     // px += R2 qz
+            "v_pk_fma_f32 %1, %11, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                      // py += R5 qz
+            "v_pk_fma_f32 %2, %13, %5, %2 op_sel_hi:[0,1,1]\n\t"                                     // pz += R8 qz
+            "s_nop 0"
+            : "=&v"(px), "=&v"(py), "=&v"(pz), "=&v"(qx), "=&v"(qy), "=&v"(qz)
+            : "v"(x), "v"(y), "v"(z), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5));
+        o.px = px; o.py = py; o.pz = pz;
+    }
     // cloud2idx (utils.py:44-59): gx = 1 - (atan2(py, a) + pi)/pi = -phi/pi ; gy = 2 theta/pi - 1
     f2 a = o.px + F2(1e-6f), b = o.pz + F2(1e-6f);
     o.rho2 = pcl_fma2(o.px, o.px, o.py * o.py);
@@ -242,8 +272,8 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     // (the constants carry the 1/255 of RGBA8 levels)
     // (a wave-uniform "no lane is clipped" fast path was tried: the extra basic block costs more in scheduling and
     // registers than the four selects it saves — 155 vs 141 us at cfg 2)
-    o.mphi = (f2){phi.x == phic.x ? dm.k_phi : 0.f, phi.y == phic.y ? dm.k_phi : 0.f};
-    o.mth = (f2){elev.x == elc.x ? dm.k_theta : 0.f, elev.y == elc.y ? dm.k_theta : 0.f};
+    o.in_phi0 = phi.x == phic.x; o.in_phi1 = phi.y == phic.y;
+    o.in_th0 = elev.x == elc.x; o.in_th1 = elev.y == elc.y;
 }
 
 // Phase B: bilinear colour, mask, residual, gradient, accumulate.
@@ -312,7 +342,10 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
         }
         f2 sx = pcl_fma2(d0, dh0, pcl_fma2(d1, dh1, d2 * dh2));
         f2 sy = pcl_fma2(d0, dv[0], pcl_fma2(d1, dv[1], d2 * dv[2]));
-        f2 dphi = sx * (o.mphi * rn), dth = sy * (o.mth * rn);                    // dL/dphi, dL/dtheta
+        // dL/dphi, dL/dtheta: the clip flag selects 1/||d|| or 0 (a select between two registers: selecting the CONSTANT
+        // k_phi / k_theta under an SGPR lane mask needs a v_mov of the constant first, one scalar operand per VALU op)
+        f2 rphi = {o.in_phi0 ? rn.x : 0.f, o.in_phi1 ? rn.y : 0.f}, rth = {o.in_th0 ? rn.x : 0.f, o.in_th1 ? rn.y : 0.f};
+        f2 dphi = (sx * F2(dm.k_phi)) * rphi, dth = (sy * F2(dm.k_theta)) * rth;
         // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
         f2 a = px + F2(1e-6f), b = pz + F2(1e-6f), rho = o.rho2 * o.rinv;
         f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, o.rho2);
