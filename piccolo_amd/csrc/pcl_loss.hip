@@ -129,19 +129,19 @@ template <> struct PclTaps<PCL_PANO_F16> { pcl_i4 top, bot; };  // two half4 tex
 
 __device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_U8>& o)
 {
-    int voff = (y0 * Wp + x0) * 4;
+    int voff = (int)(__umul24((unsigned)y0, (unsigned)Wp) + (unsigned)x0) * 4;     // v_mad_u32_u24: full rate (v_mul_lo_u32 is quarter rate)
     o.top = pcl_texel_pair_u8(tex, voff, 0);
     o.bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
 }
 __device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_F16>& o)
 {
-    int voff = (y0 * Wp + x0) * 8;
+    int voff = (int)(__umul24((unsigned)y0, (unsigned)Wp) + (unsigned)x0) * 8;
     o.top = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0);
     o.bot = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0);
 }
 __device__ __forceinline__ void pcl_issue_taps(__amdgpu_buffer_rsrc_t tex, int x0, int y0, int Wp, PclTaps<PCL_PANO_F32>& o)
 {
-    o.voff = (y0 * Wp + x0) * 16;
+    o.voff = (int)(__umul24((unsigned)y0, (unsigned)Wp) + (unsigned)x0) * 16;
     o.row = Wp * 16;
 }
 // the 12 tap components as floats (RGBA8: levels 0..255, one v_cvt_f32_ubyteN each)
