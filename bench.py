@@ -108,6 +108,7 @@ def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=12.0):
 def lookup_roofs(path, workload, poses_per_launch, fmt_name):
     """Counter-derived figures for exactly this launch shape (profiles/roofs.json, written by profiles/summarize.py from
     the rocprofv3 --pmc passes); None when the run's shape was never profiled."""
+    workload = {"cfg4": "cfg2"}.get(workload, workload)      # cfg 4 = cfg 2's cloud, panorama size and candidates per image
     key = "%s/poses%d/%s" % (workload, poses_per_launch, fmt_name)
     try:
         return key, json.load(open(path)).get(key)
@@ -183,7 +184,11 @@ def main():
         # auto: about 256 poses per launch, in EQUAL groups when the step count allows it (every timed launch then has
         # one shape, the one the counter passes under profiles/ were taken for): the largest divisor of K that is at most
         # 256 // B and at least half of it; otherwise groups of 256 // B with a shorter last one
-        target = max(1, min(256 // B, K))
+        # ... and no more images than keep their packed panoramas (8 B per texel) within ~half of the 256 MiB Infinity
+        # Cache: cfg 5's 4096x2048 panoramas are 67 MB each (measured 330 / 328 / 312 candidate-poses/s at 1 / 2 / 4 images
+        # per launch), cfg 2's 16.8 MB (3260 / 3314 / 3295 at 4 / 8 / 16)
+        cache_cap = max(1, int(140e6 // ((H + 2) * (W + 2) * 8)))
+        target = max(1, min(256 // B, K, cache_cap))
         divs = [d for d in range(target, 0, -1) if K % d == 0 and 2 * d >= target]
         ipl = divs[0] if divs else target
     # warm-up steps refine their OWN images (ids beyond every rank's timed ones), in whole launch groups of the timed size

@@ -1,14 +1,17 @@
 #!/bin/bash
 # Everything profiles/rNN/ is built from, in one go on the GPU box:  bash profiles/collect_all.sh r02
 R=${1:-r02}
-PMC="--steps 8 --warmup 0 --prewarm-ms 0 --no-cpu-baseline"
+PMC="--steps 8 --warmup 2 --no-cpu-baseline"
 ROOF_KEY=cfg2/poses256/f16 POINT_POSES=256e6 ROOF_SOURCE=$R/a_default_cfg2_8images ROOF_CMD="bench.py (default)" \
   bash profiles/collect.sh ${R}_a --workload cfg2 $PMC
 ROOF_KEY=cfg2/poses32/f16 POINT_POSES=32e6 ROOF_SOURCE=$R/b_cfg2_single_image ROOF_CMD="bench.py --images-per-launch 1" \
   bash profiles/collect.sh ${R}_b --workload cfg2 --images-per-launch 1 $PMC
 ROOF_KEY=cfg5/poses128/f16 POINT_POSES=1280e6 ROOF_SOURCE=$R/c_cfg5 ROOF_CMD="bench.py --workload cfg5 --steps 4" \
-  bash profiles/collect.sh ${R}_c --workload cfg5 --steps 4 --warmup 0 --prewarm-ms 0 --no-cpu-baseline
+  bash profiles/collect.sh ${R}_c --workload cfg5 --steps 4 --warmup 1 --no-cpu-baseline
 ROOF_KEY=cfg3/poses256/f16 POINT_POSES=256e6 ROOF_SOURCE=$R/d_cfg3 ROOF_CMD="bench.py --workload cfg3 --steps 2" \
-  bash profiles/collect.sh ${R}_d --workload cfg3 --steps 2 --warmup 0 --prewarm-ms 0 --no-cpu-baseline
+  bash profiles/collect.sh ${R}_d --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline
 bash profiles/collect.sh ${R}_e --script tools/init_bench.py
 bash profiles/collect.sh ${R}_f --script tools/chain_bench.py 167000 6 1
+# the driver's own command line (--steps 20 --warmup 5): 4 launch groups of 5 images = 160 poses per launch
+ROOF_KEY=cfg2/poses160/f16 POINT_POSES=160e6 ROOF_SOURCE=$R/g_driver_cfg2_5images ROOF_CMD="bench.py --steps 20 --warmup 5" \
+  bash profiles/collect.sh ${R}_g --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline
