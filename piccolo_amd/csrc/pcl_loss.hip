@@ -396,6 +396,9 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
     // other seven carried 5 % more than their share, tools/block_trace.py)
     int first = chunk * a.steps_base + min(chunk, a.steps_rem);
     int nsteps = a.steps_base + (chunk < a.steps_rem ? 1 : 0);
+    // (Measured and rejected for the 1800-pose launch of trim_input_loss: walking the pose groups in super-groups of 19..152
+    // groups, so that an XCD stays in one part of the panorama — 4.73 -> 4.69 ms with RGBA8 texels, 5.10 -> 5.04 ms with
+    // fp16-level texels, which stay slower there despite 10 % fewer instructions.)
     // (Measured and rejected: giving neighbouring work items different lengths — chunk pairs with their boundary moved by
     // 1/8..3/8 of a chunk — so that blocks resident together do not run their prologues / epilogues in phase: monotonically
     // slower, 124 -> 131 -> 137 us at cfg 2 for shifts of 1 / 2 steps: the longest block sets the tail.)
