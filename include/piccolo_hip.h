@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 3 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops */
+#define PCL_ABI_VERSION 4 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -191,6 +191,11 @@ int pcl_make_pano(const float *xyz_cam, const float *rgb, int64_t n, int H, int 
  * image's non-black pixels.  inter [ncand][(nsh-2)*nsw], nproj [ncand][..] = pixels histogrammed, nimg [..] likewise
  * for the query.  The caller forms score = sum_j inter / (nsh*nsw) with the reference's empty-block rule. */
 size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw);
+/* Same for a cloud of n points, large enough for the tile-binned render (ABI v4): every candidate's points are binned by the
+ * 64 x 64-pixel image tile(s) their 3 x 3 splat touches and every tile is resolved and histogrammed in LDS — no z-buffer in
+ * HBM, bit-identical scores.  pcl_hist_trim_scores takes that path when its workspace is at least this large (4 n list
+ * entries of 12 bytes per candidate: the exact worst case) and the z-buffer splat otherwise. */
+size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw);
 int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, int H, int W, const float *trans,
                          const float *rot, int ncand, int nsh, int nsw, float *inter, int32_t *nproj, int32_t *nimg,
                          void *workspace, size_t workspace_bytes, void *stream);

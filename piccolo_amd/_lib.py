@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
@@ -42,6 +42,7 @@ SIGNATURES = {
     "pcl_gd_state_bytes": (_sz, [_int]),
     "pcl_gd_workspace_bytes": (_sz, [_i64, _int, _int, _int, _c.POINTER(GdHyper)]),
     "pcl_hist_trim_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
+    "pcl_hist_trim_workspace_bytes_n": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "pcl_hist_trim_scores": (_int, [_vp, _i64, _vp, _int, _int, _vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcl_color_template_bytes": (_sz, [_i64]),
     "pcl_color_template_workspace_bytes": (_sz, [_i64]),

@@ -10,6 +10,8 @@
 // The reference renders one candidate at a time (argsort + nine index_put_ passes) and builds every histogram with a
 // dozen tensor ops; the rendered image is never materialised here.
 // Only the middle block rows h = 1 .. num_split_h - 2 are used (utils.py:556); block j <-> (h = 1 + j / nsw, w = j % nsw).
+#include <stdlib.h>
+
 #include "pcl_device.h"
 
 #define PCL_HBINS 512   // 8 x 8 x 8
@@ -100,6 +102,231 @@ __device__ inline int pcl_hist_code(float r, float g, float b)
     // value.long() // ceil(255 / 8) per channel, r + 8 g + 64 b (color_utils.py:86-95)
     return ((int)r >> 5) + 8 * ((int)g >> 5) + 64 * ((int)b >> 5);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Tile-binned render + histogram (round 2): no z-buffer in HBM.
+// The splat path above pays ~2 global 64-bit atomics per rendered pixel (the LDS windows of neighbouring blocks overlap),
+// a 16 MB-per-candidate z-buffer fill and a second pass that reads it back (rocprofv3, profiles/r02/e_init_stage_*: splat 659
+// us per 16 candidates with the VALUs 34 % busy, 530 MB of atomic traffic; fill 49 us; accumulate 123 us).  Here every
+// candidate's points are first BINNED by the 64 x 64-pixel image tile(s) their 3 x 3 splat touches (count -> scan ->
+// scatter of packed point slots, block-aggregated in LDS: one global atomic per (block, tile)); then one workgroup per
+// (tile, candidate) resolves its tile completely in LDS with the very same 64-bit priority keys and histograms the winners
+// straight into the block histograms.  Same keys, same winners, same integer counts as the splat path (bit-identical scores,
+// tests/test_hip_harness.py).  The point lists live where the z-buffer would have been.
+#define PCL_TS 64                      // tile edge in pixels
+#define PCL_TS_SHIFT 6
+
+struct PclBinArgs {
+    const float* cloud;
+    int64_t n, stride;
+    const PclPoseRec* poses;
+    int H, W, ntx, nt;                 // tiles per row, tiles per image
+    int* counts;                       // [ncand][nt]      points (with multiplicity) per tile
+    int* offsets;                      // [ncand][nt + 1]  exclusive scan of counts
+    int* cursors;                      // [ncand][nt]      scatter cursors
+    int* order;                        // [ncand][nt]      tiles by decreasing count: the resolve kernel's launch order
+    uint32_t* lists;                   // [ncand][3][cap]  per entry: pixel (row << 16 | col), depth bits, packed point slot
+    int64_t cap;                       // entries per candidate (4 n: a 3 x 3 splat touches at most four tiles)
+};
+
+// pixel of packed point i for pose pr, exactly as pcl_splat_poses_kernel computes it
+__device__ __forceinline__ void pcl_bin_project(const PclBinArgs& a, const PclPoseRec* __restrict__ pr, int64_t i, int& row, int& col, float& d)
+{
+    float qx = a.cloud[i] - pr->t[0], qy = a.cloud[a.stride + i] - pr->t[1], qz = a.cloud[2 * a.stride + i] - pr->t[2];
+    float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+    float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+    float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
+    pcl_pano_pixel_ref(px, py, pz, a.H, a.W, row, col);
+    d = sqrtf(px * px + py * py + pz * pz);
+}
+
+// the (up to four) tiles a 3 x 3 splat centred on (row, col) touches, after the clamp to the image
+__device__ __forceinline__ int pcl_bin_tiles(int row, int col, int H, int W, int ntx, int tiles[4])
+{
+    int ra = max(row - 1, 0) >> PCL_TS_SHIFT, rb = min(row + 1, H - 1) >> PCL_TS_SHIFT;
+    int ca = max(col - 1, 0) >> PCL_TS_SHIFT, cb = min(col + 1, W - 1) >> PCL_TS_SHIFT;
+    int k = 0;
+    tiles[k++] = ra * ntx + ca;
+    if (cb != ca) tiles[k++] = ra * ntx + cb;
+    if (rb != ra) {
+        tiles[k++] = rb * ntx + ca;
+        if (cb != ca) tiles[k++] = rb * ntx + cb;
+    }
+    return k;
+}
+
+// SCATTER = false: count; true: reserve a range per (block, tile) and write the entries.  A block takes PCL_BIN_PTS
+// consecutive (Morton-ordered) points: the zeroing and the flush of the nt LDS counters are per block, and with 256 points
+// per block they were most of the kernel (114 / 189 us per 16 candidates at 1M points; a wave-aggregated LDS add instead of
+// one atomic per lane did not help: 130 / 213 us).
+#define PCL_BIN_PTS 2048
+template <bool SCATTER>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
+{
+    constexpr int PER = PCL_BIN_PTS / PCL_BLOCK;
+    extern __shared__ int lds[];                       // cnt[nt] (+ base[nt] when scattering)
+    int* cnt = lds;
+    int* base = lds + a.nt;
+    const int cand = blockIdx.y;
+    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cnt[t] = 0;
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
+    int tiles[PER][4], ntl[PER];
+    uint32_t pix[PER], dep[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int64_t i = first + (int64_t)k * PCL_BLOCK;
+        ntl[k] = 0;
+        if (i < a.n) {
+            int row, col;
+            float d;
+            pcl_bin_project(a, a.poses + cand, i, row, col, d);
+            ntl[k] = pcl_bin_tiles(row, col, a.H, a.W, a.ntx, tiles[k]);
+            pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
+            dep[k] = __float_as_uint(d);
+            for (int j = 0; j < ntl[k]; j++) atomicAdd(&cnt[tiles[k][j]], 1);
+        }
+    }
+    __syncthreads();
+    if (!SCATTER) {
+        int* g = a.counts + (int64_t)cand * a.nt;
+        for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK)
+            if (cnt[t]) atomicAdd(&g[t], cnt[t]);
+        return;
+    }
+    int* cur = a.cursors + (int64_t)cand * a.nt;
+    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
+        int c = cnt[t];
+        base[t] = c ? atomicAdd(&cur[t], c) : 0;       // this block's range inside the tile's list
+        cnt[t] = 0;                                    // becomes the block-local cursor
+    }
+    __syncthreads();
+    const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
+    uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int64_t i = first + (int64_t)k * PCL_BLOCK;
+        for (int j = 0; j < ntl[k]; j++) {
+            const int t = tiles[k][j];
+            const int pos = off[t] + base[t] + atomicAdd(&cnt[t], 1);
+            // the projection travels with the entry: the resolve kernel reads 12 coalesced bytes per entry instead of chasing
+            // slot -> x, y, z and projecting a third time
+            list[pos] = pix[k];
+            list[a.cap + pos] = dep[k];
+            list[2 * a.cap + pos] = (uint32_t)i;
+        }
+    }
+}
+
+// exclusive scan of the tile counts of one candidate; also zeroes its cursors
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_scan_kernel(PclBinArgs a)
+{
+    __shared__ int part[PCL_BLOCK];
+    const int cand = blockIdx.x;
+    const int* cnt = a.counts + (int64_t)cand * a.nt;
+    int* off = a.offsets + (int64_t)cand * (a.nt + 1);
+    int* cur = a.cursors + (int64_t)cand * a.nt;
+    const int per = (a.nt + PCL_BLOCK - 1) / PCL_BLOCK, lo = threadIdx.x * per, hi = min(lo + per, a.nt);
+    int s = 0;
+    for (int t = lo; t < hi; t++) s += cnt[t];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < PCL_BLOCK; k++) { int v = part[k]; part[k] = run; run += v; }
+        off[a.nt] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int t = lo; t < hi; t++) { off[t] = run; run += cnt[t]; cur[t] = 0; }
+    // Longest first: a far wall seen from the other end of the room puts 40k points into one tile (20x the mean); a heavy
+    // tile that starts late IS the kernel's tail.  Rank by count (ties by index): order[rank] = tile.
+    extern __shared__ int cl[];                        // the counts, for the nt^2 comparisons
+    int* ord = a.order + (int64_t)cand * a.nt;
+    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cl[t] = cnt[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
+        const int c = cl[t];
+        int rank = 0;
+        for (int u = 0; u < a.nt; u++) {
+            const int cu = cl[u];
+            rank += (cu > c || (cu == c && u < t)) ? 1 : 0;
+        }
+        ord[rank] = t;
+    }
+}
+
+// One workgroup per (tile, candidate): resolve the tile in LDS (same keys as the splat path), then histogram the winners of
+// the pixels where the query image is not black into the block histograms (LDS for the up to 2 x 2 histogram blocks a tile
+// overlaps; tiny blocks — more than that per tile — go to the global counters directly).
+// (1024 threads: the heaviest tile of a candidate — up to 20x the mean — sets the duration of the launch)
+#define PCL_RESOLVE_THREADS 1024
+__global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, const float* __restrict__ img, int nsh, int nsw,
+                                                                          unsigned int* __restrict__ ghist)
+{
+    __shared__ unsigned long long tile[PCL_TS * PCL_TS];
+    __shared__ unsigned int hist[4][PCL_HBINS];
+    const int cand = blockIdx.y;
+    const int t = a.order[(int64_t)cand * a.nt + blockIdx.x];          // heaviest tiles first
+    const int ty = t / a.ntx, tx = t - ty * a.ntx;
+    const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
+    const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
+    for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
+    for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
+    const uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
+    const int e0 = off[t], e1 = off[t + 1];
+    for (int e = e0 + threadIdx.x; e < e1; e += PCL_RESOLVE_THREADS) {
+        const uint32_t pix = list[e], dbits = list[a.cap + e], i = list[2 * a.cap + e];
+        const int row = (int)(pix >> 16), col = (int)(pix & 0xffffu);
+        const unsigned long long bk = ((unsigned long long)dbits << 29) | (unsigned long long)(0x1fffffffu - i);
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            int r = min(max(row + drow[p], 0), a.H - 1), c = min(max(col + dcol[p], 0), a.W - 1);
+            if ((r >> PCL_TS_SHIFT) == ty && (c >> PCL_TS_SHIFT) == tx) {
+                // a plain read first: cells only ever decrease, so a key that does not beat what is already there can be
+                // dropped without the atomic (in the dense tiles — a far wall seen from the other end of the room puts
+                // 40k points into one tile, 20x the mean — almost every key loses)
+                unsigned long long* cell = &tile[(r & (PCL_TS - 1)) * PCL_TS + (c & (PCL_TS - 1))];
+                const unsigned long long key = ((unsigned long long)(8 - p) << 60) | bk;
+                if (key < *(volatile unsigned long long*)cell) atomicMin(cell, key);
+            }
+        }
+    }
+    __syncthreads();
+    const int bh = a.H / nsh, bw = a.W / nsw, nblk = (nsh - 2) * nsw;
+    const int h_lo = (ty * PCL_TS) / bh, w_lo = (tx * PCL_TS) / bw;       // first histogram block row / column of this tile
+    unsigned int* g = ghist + (int64_t)cand * nblk * PCL_HBINS;
+    for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) {
+        const unsigned long long k = tile[i];
+        const int r = ty * PCL_TS + (i >> PCL_TS_SHIFT), c = tx * PCL_TS + (i & (PCL_TS - 1));
+        if (k == ~0ull || r >= a.H || c >= a.W) continue;
+        const int h = r / bh, w = c / bw;
+        if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // only the middle block rows (utils.py:556)
+        const int64_t pix = (int64_t)r * a.W + c;
+        const float q0 = img[3 * pix], q1 = img[3 * pix + 1], q2 = img[3 * pix + 2];
+        if (q0 == 0.f && q1 == 0.f && q2 == 0.f) continue;               // query pixel black
+        const int64_t j = (int64_t)(0x1fffffffu - (uint32_t)(k & 0x1fffffffull));
+        // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
+        const float p0 = -a.cloud[3 * a.stride + j] * 255.f, p1 = -a.cloud[4 * a.stride + j] * 255.f, p2 = -a.cloud[5 * a.stride + j] * 255.f;
+        if (p0 == 0.f && p1 == 0.f && p2 == 0.f) continue;
+        const int code = pcl_hist_code(p0, p1, p2), blk = (h - 1) * nsw + w;
+        const int sh = h - h_lo, sw = w - w_lo;
+        if (sh < 2 && sw < 2) atomicAdd(&hist[sh * 2 + sw][code], 1u);
+        else atomicAdd(&g[(int64_t)blk * PCL_HBINS + code], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) {
+        const unsigned int v = (&hist[0][0])[i];
+        if (!v) continue;
+        const int slot = i / PCL_HBINS, code = i - slot * PCL_HBINS;
+        const int h = h_lo + (slot >> 1), w = w_lo + (slot & 1);
+        if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // (cannot hold counts: guarded when accumulated)
+        atomicAdd(&g[(int64_t)((h - 1) * nsw + w) * PCL_HBINS + code], v);
+    }
+}
+
 
 // Histograms in two steps so that a handful of image blocks still fills the chip: every (block, candidate) is cut into
 // PCL_HSUB pixel ranges, each range is histogrammed in LDS by its own workgroup and its non-empty bins are added to a
@@ -192,12 +419,39 @@ __global__ void pcl_hist_pose_setup_kernel(const float* __restrict__ trans, cons
 
 static size_t hist_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw)
+static int pcl_hist_env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// bytes of the render area per candidate: the z-buffer of the splat path, or — when n is given — the larger of that and the
+// tile-binned path's bookkeeping + point lists (4 n entries of 12 bytes: the exact worst case, nothing can overflow)
+static size_t hist_render_bytes(int64_t n, int H, int W)
+{
+    size_t zb = (size_t)H * W * 8;
+    if (n <= 0) return zb;
+    const size_t nt = (size_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
+    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12;
+    return binned > zb ? binned : zb;
+}
+
+static size_t hist_workspace_bytes(int64_t n, int ncand, int H, int W, int nsh, int nsw)
 {
     if (ncand <= 0 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return 0;
     const size_t nblk = (size_t)(nsh - 2) * nsw;
-    return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * H * W * 8) +
+    return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * hist_render_bytes(n, H, W)) +
            hist_align(nblk * PCL_HBINS * sizeof(float)) + hist_align((size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int));
+}
+
+extern "C" size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw)
+{
+    return n > 0 ? hist_workspace_bytes(n, ncand, H, W, nsh, nsw) : 0;
+}
+
+extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw)
+{
+    return hist_workspace_bytes(0, ncand, H, W, nsh, nsw);
 }
 
 extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* img_hwc, int H, int W,
@@ -208,12 +462,15 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     if (n <= 0 || n > 0x1fffffffll || ncand <= 0 || ncand > 65535 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
     if (H / nsh <= 0 || W / nsw <= 0) return PCL_EINVAL;
     if (workspace_bytes < pcl_hist_trim_workspace_bytes(ncand, H, W, nsh, nsw)) return PCL_EWORKSPACE;
+    // a workspace of pcl_hist_trim_workspace_bytes_n(n, ...) selects the tile-binned path, the smaller one of
+    // pcl_hist_trim_workspace_bytes(...) the z-buffer splat
+    const bool roomy = workspace_bytes >= hist_workspace_bytes(n, ncand, H, W, nsh, nsw);
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     PclPoseRec* recs = (PclPoseRec*)ws;
     ws += hist_align((size_t)ncand * sizeof(PclPoseRec));
     unsigned long long* zbuf = (unsigned long long*)ws;
-    ws += hist_align((size_t)ncand * H * W * 8);
+    ws += hist_align((size_t)ncand * hist_render_bytes(roomy ? n : 0, H, W));
     float* qhist = (float*)ws;
     const int nblk = (nsh - 2) * nsw;
     ws += hist_align((size_t)nblk * PCL_HBINS * sizeof(float));
@@ -221,21 +478,43 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     unsigned int* ghist_c = ghist_q + (size_t)nblk * PCL_HBINS;
     (void)hipMemsetAsync(ghist_q, 0, (size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int), s);
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
-    hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
     const int64_t stride = pcl_cloud_stride(n);
-    // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
-    // patch whose splats nearly all land inside the window.  Measured at cfg-2 size, 64 candidates (whole trimming
-    // stage): 7.6 ms with 2048 points per block — their patch is wider than the window at close range and the overflow
-    // goes to global atomics one splat at a time —, 5.4 / 4.2 / 3.6 ms with 1024 / 512 / 256; other windows at
-    // 256-512 points: 64x96 3.8, 48x64 4.5, 48x48 4.0 ms.
-    constexpr int TH = 64, TW = 64, PTS = 256;
-    hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
-                       dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
     hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
                        cloud, stride, img_hwc, H, W, nsh, nsw, ghist_q);
     hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj);
-    hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W,
-                       nsh, nsw, ghist_c);
+    // Tile-binned path when the caller sized the workspace for it.  PCL_HIST_SPLAT=1 forces the z-buffer path (tests compare
+    // the two bit for bit).
+    const int force_splat = pcl_hist_env_int("PCL_HIST_SPLAT", 0);      // (read per call: a handful of calls per image)
+    const int ntx = (W + PCL_TS - 1) / PCL_TS, nty = (H + PCL_TS - 1) / PCL_TS, nt = ntx * nty;
+    const int64_t cap = 4 * n;
+    if (!force_splat && roomy && nt <= 4096 && H < 65536 && W < 65536 && n < ((int64_t)1 << 28)) {
+        PclBinArgs b;
+        b.cloud = cloud; b.n = n; b.stride = stride; b.poses = recs; b.H = H; b.W = W; b.ntx = ntx; b.nt = nt;
+        // layout of the render area: [ncand] x { counts[nt], offsets[nt + 1], cursors[nt], order[nt] }, [ncand] x lists[3][cap]
+        int* ints = (int*)zbuf;
+        b.counts = ints; b.offsets = ints + (int64_t)ncand * nt; b.cursors = b.offsets + (int64_t)ncand * (nt + 1);
+        b.order = b.cursors + (int64_t)ncand * nt;
+        b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
+        b.cap = cap;
+        (void)hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
+        dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
+        hipLaunchKernelGGL(pcl_bin_kernel<false>, pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+        hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+        hipLaunchKernelGGL(pcl_bin_kernel<true>, pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+        hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel, dim3(nt, ncand), dim3(PCL_RESOLVE_THREADS), 0, s, b, img_hwc, nsh, nsw, ghist_c);
+    } else {
+        hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
+        // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
+        // patch whose splats nearly all land inside the window.  Measured at cfg-2 size, 64 candidates (whole trimming
+        // stage): 7.6 ms with 2048 points per block — their patch is wider than the window at close range and the overflow
+        // goes to global atomics one splat at a time —, 5.4 / 4.2 / 3.6 ms with 1024 / 512 / 256; other windows at
+        // 256-512 points: 64x96 3.8, 48x64 4.5, 48x48 4.0 ms.
+        constexpr int TH = 64, TW = 64, PTS = 256;
+        hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
+                           dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
+        hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W,
+                           nsh, nsw, ghist_c);
+    }
     hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj);
     PCL_LAUNCH_CHECK();
     return 0;
@@ -248,33 +527,54 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
 // value), NaNs cleaned to 0 in place (utils.py:579).  score = sum of the slots / (nsh * nsw) (utils.py:580).  Pinned by
 // G19 (per-candidate slot vectors read out of the running reference function).
 // The carry makes the candidates a sequential chain per slot: one block, thread j owns slot j (strided if there are more
-// slots than threads) and walks the candidates in order, its carried value in LDS; thread 0 sums each candidate's slots in
-// slot order (deterministic).  K is a few dozen candidates, nblk a few dozen slots: microseconds.
+// slots than threads) and walks the candidates in order with its carried value in a register, writing the slot's content
+// after every candidate to LDS; then one thread per candidate sums that candidate's slots in slot order (deterministic).
+// Candidates go through in chunks that fit the LDS table; no barrier inside the walk (the first version synchronised twice
+// per candidate: 78 us per call for 64 candidates).
+#define PCL_SCORE_LDS_FLOATS 6144
 __global__ void __launch_bounds__(256) pcl_hist_score_kernel(const float* __restrict__ inter, const int* __restrict__ nproj,
                                                              const int* __restrict__ nimg, int ncand, int nsh, int nsw,
                                                              float* __restrict__ score)
 {
-    extern __shared__ float slot[];                       // [nblk] current content of hist_intersect_split (middle rows)
+    __shared__ float eff[PCL_SCORE_LDS_FLOATS];           // [chunk][nblk]: slot contents after each candidate of the chunk
+    __shared__ float carry_slot[1024];                    // carried slot values between chunks (nblk <= 1024)
+    __shared__ int brk[PCL_SCORE_LDS_FLOATS];             // [chunk][rows]: first empty block of the row (nsw if none)
     const int nblk = (nsh - 2) * nsw;
-    for (int j = threadIdx.x; j < nblk; j += blockDim.x) slot[j] = 0.f;
+    const int chunk = max(1, PCL_SCORE_LDS_FLOATS / nblk);
+    for (int j = threadIdx.x; j < nblk; j += blockDim.x) carry_slot[j] = 0.f;
     __syncthreads();
-    for (int cand = 0; cand < ncand; cand++) {
-        const int* np = nproj + (int64_t)cand * nblk;
-        for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
-            const int row0 = (j / nsw) * nsw;
-            int first_empty = nsw;                        // position in the row where the reference breaks
-            for (int w = 0; w < nsw; w++)
-                if (np[row0 + w] == 0 || nimg[row0 + w] == 0) { first_empty = w; break; }
-            const int w = j - row0;
-            if (w < first_empty) {
-                float v = inter[(int64_t)cand * nblk + j];
-                slot[j] = (v == v) ? v : 0.f;
-            } else if (w == first_empty) slot[j] = 0.f;   // (w > first_empty: untouched, keeps the earlier candidate's value)
+    const int nrows = nsh - 2;
+    for (int c0 = 0; c0 < ncand; c0 += chunk) {
+        const int c1 = min(c0 + chunk, ncand);
+        // stage the chunk: the intersections (NaN -> 0) and, per (candidate, block row), where the reference breaks
+        for (int i = threadIdx.x; i < (c1 - c0) * nblk; i += blockDim.x) {
+            float v = inter[(int64_t)c0 * nblk + i];
+            eff[i] = (v == v) ? v : 0.f;
+        }
+        for (int i = threadIdx.x; i < (c1 - c0) * nrows; i += blockDim.x) {
+            const int cand = c0 + i / nrows, row0 = (i % nrows) * nsw;
+            const int* np = nproj + (int64_t)cand * nblk;
+            int first_empty = nsw;
+            for (int ww = 0; ww < nsw; ww++)
+                if (np[row0 + ww] == 0 || nimg[row0 + ww] == 0) { first_empty = ww; break; }
+            brk[i] = first_empty;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        for (int j = threadIdx.x; j < nblk; j += blockDim.x) {
+            const int row = j / nsw, w = j - row * nsw;
+            float carry = carry_slot[j];
+            for (int cand = c0; cand < c1; cand++) {
+                const int first_empty = brk[(cand - c0) * nrows + row];
+                if (w < first_empty) carry = eff[(cand - c0) * nblk + j];
+                else if (w == first_empty) carry = 0.f;   // (w > first_empty: untouched, keeps the earlier candidate's value)
+                eff[(cand - c0) * nblk + j] = carry;
+            }
+            carry_slot[j] = carry;
+        }
+        __syncthreads();
+        for (int cand = c0 + threadIdx.x; cand < c1; cand += blockDim.x) {
             float total = 0.f;
-            for (int j = 0; j < nblk; j++) total += slot[j];
+            for (int j = 0; j < nblk; j++) total += eff[(cand - c0) * nblk + j];
             score[cand] = total / (float)(nsh * nsw);
         }
         __syncthreads();
@@ -285,9 +585,8 @@ extern "C" int pcl_hist_trim_reduce(const float* inter, const int32_t* nproj, co
                                     void* stream)
 {
     if (!inter || !nproj || !nimg || !score || ncand <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
-    const size_t lds = (size_t)(nsh - 2) * nsw * sizeof(float);
-    if (lds > 60000) return PCL_EINVAL;                   // > 15000 blocks: not a block grid this stage is meant for
-    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw, score);
+    if ((nsh - 2) * nsw > 1024) return PCL_EINVAL;        // > 1024 blocks: not a block grid this stage is meant for
+    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw, score);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -128,9 +128,10 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
-def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16):
+def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16, return_parts=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
-    `cloud` is a packed Cloud.  Candidates are processed `batch` at a time (one z-buffer of H*W*8 bytes each)."""
+    `cloud` is a packed Cloud.  Candidates are processed `batch` at a time (H*W*8 bytes of workspace each: the point lists
+    of the tile-binned render, or the z-buffer of the splat path).  return_parts: (scores, inter, nproj, nimg)."""
     lib = _lib.load()
     img = _dev(img)
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
@@ -139,7 +140,10 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16)
     inter = torch.empty(K, nblk, dtype=F32, device=img.device)
     nproj = torch.empty(K, nblk, dtype=torch.int32, device=img.device)
     nimg = torch.empty(nblk, dtype=torch.int32, device=img.device)
-    nws = lib.pcl_hist_trim_workspace_bytes(min(batch, K), H, W, num_split_h, num_split_w)
+    # workspace for the tile-binned render (48 B per point and candidate in the worst case): keep a batch within ~2 GB
+    per_cand = max(lib.pcl_hist_trim_workspace_bytes_n(cloud.n, 1, H, W, num_split_h, num_split_w), 1)
+    batch = max(1, min(batch, K, int(2e9 // per_cand)))
+    nws = lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w)
     if nws == 0:
         raise ValueError("hist_trim_scores: need num_split_h >= 3 and blocks of at least one pixel")
     ws = _bytes(nws)
@@ -152,6 +156,8 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=16)
     scores = torch.empty(K, dtype=F32, device=img.device)
     _lib.check(lib.pcl_hist_trim_reduce(_ptr(inter), _ptr(nproj), _ptr(nimg), K, num_split_h, num_split_w, _ptr(scores), _stream()),
                "pcl_hist_trim_reduce")
+    if return_parts:
+        return scores, inter, nproj, nimg
     return scores
 
 

@@ -344,3 +344,39 @@ def test_small_problems_replay_a_cached_graph_and_stay_bit_identical(oracle):
     m_graph = po.omniloc_batch_images(imgs, X, C, [t.clone() for t in trs], [r.clone() for r in ros], Cfg(**base))
     for a, b in zip(m_eager, m_graph):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
+    """The tile-binned render + histogram (no z-buffer in HBM) uses the same 64-bit priority keys as the z-buffer splat:
+    same winners, same integer histogram counts, hence BIT-identical intersections, counts and scores — on the golden
+    scenes (tiles larger than the histogram blocks: the direct-to-global branch) and on a 512 x 1024 panorama with 200k
+    points (tiles inside histogram blocks, several tiles per block, points on tile borders, ragged image edges)."""
+    import os
+    from piccolo_amd import ops, synth
+    cases = []
+    g = load_golden("g12_trim_input_hist.npz")
+    cases.append((g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], 4, 4))
+    g = load_golden("g19_trim_hist_empty_blocks.npz")
+    cases.append((g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], 4, 4))
+    for (n, H, W, nh, nw) in ((200_000, 512, 1024, 4, 4), (60_000, 200, 330, 5, 3)):
+        xyz, rgb = synth.box_room(n, 90)
+        t_gt, ypr_gt = synth.gt_pose(90)
+        X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+        img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W))).cpu().numpy()
+        tr, ro = synth.start_poses(t_gt, ypr_gt, 9, seed=90, sigma_t=0.5, sigma_r=0.4)
+        cases.append((img, xyz, rgb, tr, ro, nh, nw))
+    dev = torch.device("cuda")
+    try:
+        for img, xyz, rgb, tr, ro, nh, nw in cases:
+            I, X, C = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (img, xyz, rgb)]
+            T_, R_ = torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev)
+            cloud = ops.Cloud(X, C)
+            out = {}
+            for mode in ("1", "0"):
+                os.environ["PCL_HIST_SPLAT"] = mode
+                out[mode] = ops.hist_trim_scores(I, cloud, T_, R_, nh, nw, batch=4, return_parts=True)
+            for a, b in zip(out["1"], out["0"]):
+                assert torch.equal(a, b), (img.shape, len(xyz))
+            assert float(out["0"][0].abs().sum()) > 0
+    finally:
+        os.environ.pop("PCL_HIST_SPLAT", None)
