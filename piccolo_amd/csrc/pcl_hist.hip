@@ -1,12 +1,16 @@
 // pcl_hist.hip — the second trimming stage of the initialisation (reference utils.py:510-588, color_utils.py:68-144)
-// for a BATCH of candidate poses, fused into three kernels:
-//   1. pcl_splat_poses_kernel : make_pano's z-buffered 3x3 splat (see pcl_ops.hip) for every candidate pose at once,
+// for a BATCH of candidate poses.  Two renderers feed the same histogram counters (bit-identical results):
+//   tile-binned (default, round 2): pcl_bin_kernel<false> / pcl_bin_scan_kernel / pcl_bin_kernel<true> bin every candidate's
+//                               points by the 64 x 64-pixel tiles their 3 x 3 splats touch; pcl_tile_resolve_hist_kernel
+//                               resolves one tile per workgroup in LDS and histograms the winners — no z-buffer in HBM;
+//   z-buffer splat (round 1, kept for workspaces sized without n and as the cross-check):
+//     pcl_splat_poses_kernel  : make_pano's z-buffered 3x3 splat (see pcl_ops.hip) for every candidate pose at once,
 //                               straight from the packed world-frame cloud (p = R (x - t) computed in the kernel), with
 //                               LDS-tiled atomicMin;
-//   2. pcl_hist_accum_kernel  : per (candidate, block, pixel range): resolve the z-buffer to colours and histogram the
-//                               pixels where both the render and the query are non-black in LDS (mode 0: the query image's
-//                               own non-black pixels), merged into global counters with integer atomics;
-//   3. pcl_hist_final_kernel  : normalise (query) / intersect with the query histogram (candidates).
+//     pcl_hist_accum_kernel<1>: per (candidate, block, pixel range): resolve the z-buffer to colours and histogram the
+//                               pixels where both the render and the query are non-black in LDS;
+//   then, for both: pcl_hist_accum_kernel<0> (the query image's own non-black pixels), pcl_hist_final_kernel (normalise the
+//   query histograms / intersect the candidates' with them), pcl_hist_score_kernel (scores with the reference's slot rule).
 // The reference renders one candidate at a time (argsort + nine index_put_ passes) and builds every histogram with a
 // dozen tensor ops; the rendered image is never materialised here.
 // Only the middle block rows h = 1 .. num_split_h - 2 are used (utils.py:556); block j <-> (h = 1 + j / nsw, w = j % nsw).
