@@ -193,7 +193,8 @@ def main():
         ipl = divs[0] if divs else target
     # warm-up steps refine their OWN images (ids beyond every rank's timed ones), in whole launch groups of the timed size
     n_warm = ((Wm + ipl - 1) // ipl) * ipl if Wm > 0 else 0
-    n_img = K + n_warm
+    # (the untimed clock pre-warm needs a launch group of its own images even with --warmup 0)
+    n_img = K + max(n_warm, ipl if args.prewarm_ms > 0 else 0)
 
     # ---- untimed setup: synthetic room, one panorama per query image, everything packed and resident in HBM
     xyz, rgb = synth.box_room(N, seed=0)                      # the shared cloud, replicated on every rank
@@ -311,7 +312,7 @@ def main():
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
             refine(warm_items[0])
             torch.cuda.synchronize()
-    for it in warm_items:                                      # the W warm-up steps (distinct images)
+    for it in warm_items[:n_warm // ipl]:                      # the W warm-up steps (distinct images)
         refine(it)
     if dist is not None:                                       # first use of the collective sets up its connections: untimed
         gather_results()
