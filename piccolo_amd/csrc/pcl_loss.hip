@@ -399,6 +399,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
     // (Measured and rejected for the 1800-pose launch of trim_input_loss: walking the pose groups in super-groups of 19..152
     // groups, so that an XCD stays in one part of the panorama — 4.73 -> 4.69 ms with RGBA8 texels, 5.10 -> 5.04 ms with
     // fp16-level texels, which stay slower there despite 10 % fewer instructions.)
+    // (Measured and rejected: tapered lengths — the chunks an XCD reaches first 2..8x longer than the ones it reaches last, so
+    // that the tail of the launch consists of short blocks: 124.0 -> 122.5 us at cfg 2, within the run-to-run spread.)
     // (Measured and rejected: giving neighbouring work items different lengths — chunk pairs with their boundary moved by
     // 1/8..3/8 of a chunk — so that blocks resident together do not run their prologues / epilogues in phase: monotonically
     // slower, 124 -> 131 -> 137 us at cfg 2 for shifts of 1 / 2 steps: the longest block sets the tail.)
