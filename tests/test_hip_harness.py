@@ -358,12 +358,15 @@ def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
     cases.append((g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], 4, 4))
     g = load_golden("g19_trim_hist_empty_blocks.npz")
     cases.append((g["img"], g["xyz"], g["rgb"], g["trans"], g["rot"], 4, 4))
-    for (n, H, W, nh, nw) in ((200_000, 512, 1024, 4, 4), (60_000, 200, 330, 5, 3)):
+    # (also: fewer points than a binning block, an image smaller than one tile, image edges that cut tiles and histogram
+    # blocks, one candidate, many thin histogram rows)
+    for (n, H, W, nh, nw) in ((200_000, 512, 1024, 4, 4), (60_000, 200, 330, 5, 3), (100, 40, 50, 3, 1), (3_000, 63, 129, 3, 2),
+                              (20_000, 130, 257, 8, 5), (5_000, 64, 64, 4, 4)):
         xyz, rgb = synth.box_room(n, 90)
         t_gt, ypr_gt = synth.gt_pose(90)
         X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
         img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W))).cpu().numpy()
-        tr, ro = synth.start_poses(t_gt, ypr_gt, 9, seed=90, sigma_t=0.5, sigma_r=0.4)
+        tr, ro = synth.start_poses(t_gt, ypr_gt, 1 if n == 5_000 else 9, seed=90, sigma_t=0.5, sigma_r=0.4)
         cases.append((img, xyz, rgb, tr, ro, nh, nw))
     dev = torch.device("cuda")
     try:
