@@ -136,3 +136,54 @@ def test_cfg4_64_images_sharded_over_8_ranks(ops, oracle, parity):
         ref = oracle.sampling_loss(xyz, rgb, imgs[k].cpu().numpy(), starts[k][0][:4], starts[k][1][:4], dtype=np.float64, grad=False)
         worst = max(worst, rel(multi_first[k][:4], ref["loss"]))
     parity("iteration-0 loss vs fp64 oracle, 4 candidates x 64 images", worst, 2e-5)
+
+
+def test_full_size_initialisation_stage_vs_oracle(ops, oracle, parity):
+    """The initialisation stage at BASELINE cfg-2 size (1M points, 2048x1024, the stanford candidate grid: 75 translations x
+    24 rotations = 1800 poses): the forward-only loss table of trim_input_loss against the oracle for ALL 1800 poses, the
+    64 survivors, and the histogram-intersection scores of those 64 (tile-binned render) against the oracle's restatement
+    of trim_input_hist_secondary; then make_input's final 32 starting poses."""
+    from oracle import hist as ohist
+    from piccolo_amd import synth, utils
+    from test_hip_harness import STANFORD
+    n, H, W, K1, K2 = 1_000_000, 1024, 2048, 64, 32
+    xyz, rgb, X, C = _scene(ops, n, H, W, seed=0)
+    img, t_gt, ypr_gt = _pano(ops, X, C, H, W, image_id=3)
+    img_host = img.cpu().numpy()
+    init = dict(STANFORD)
+    rot = utils.generate_rot_points(init, device=X.device)
+    trans = utils.generate_trans_points(X, init, device=X.device)
+    assert len(trans) * len(rot) == 1800
+    # ---- loss trim: the whole table
+    cloud = ops.Cloud(X, C)
+    tt, rr = trans.repeat_interleave(len(rot), 0), rot.repeat(len(trans), 1)          # row-major (K, R) like the reference's table
+    table = ops.sampling_loss(cloud, ops.Pano(img, fmt="u8"), tt, rr, with_grad=False).cpu().numpy()
+    ref = oracle.sampling_loss(xyz, rgb, img_host, tt.cpu().numpy(), rr.cpu().numpy(), dtype=np.float64, grad=False)   # ~25 s of host cores
+    dcount = float(np.abs(table[:, 1] - ref["count"]).max())
+    parity("trim_input_loss: mask count over 1800 poses (points)", dcount, 40)
+    # (a point that is black in fp32 and not in fp64, or vice versa, moves the mean by ~1/n: measured 13 such points, 9e-6)
+    parity("trim_input_loss: loss table vs fp64 oracle (1800 poses)", rel(table[:, 0], ref["loss"]), 3e-7 + 2.0 * dcount / n)
+    t1, r1 = utils.trim_input_loss(img, X, C, trans, rot, K1)
+    # the reference's selection on the oracle's table: loss_table.argsort()[:num_input], index // R, index % R (utils.py:500-505)
+    inds = np.argsort(ref["loss"].astype(np.float32), kind="stable")[:K1]
+    ot, orr = trans.cpu().numpy()[inds // len(rot)], rot.cpu().numpy()[inds % len(rot)]
+    got = {tuple(np.round(np.r_[a, b], 5)) for a, b in zip(t1.cpu().numpy(), r1.cpu().numpy())}
+    want = {tuple(np.round(np.r_[a, b], 5)) for a, b in zip(ot, orr)}
+    # (candidates whose losses differ in the 7th digit may swap at the cut: the survivors agree but for such near-ties)
+    parity("trim_input_loss: survivors not in the oracle's top 64", len(got - want), 2)
+    assert np.array_equal(t1[0].cpu().numpy(), ot[0]) and np.array_equal(r1[0].cpu().numpy(), orr[0])          # the best pair is the same
+    # ---- histogram trim of the 64 survivors (the device's own list, so that both score the same candidates)
+    scores = ops.hist_trim_scores(img, cloud, t1, r1, init["num_split_h"], init["num_split_w"]).cpu().numpy()
+    oscores, _ = ohist.hist_scores(img_host, xyz, rgb, t1.cpu().numpy(), r1.cpu().numpy(), init["num_split_h"], init["num_split_w"])
+    parity("trim_input_hist_secondary: scores of 64 candidates vs oracle (abs, scores in 0..0.5)", np.abs(scores - oscores).max(), 2e-3)
+    top_dev, top_orc = set(np.argsort(scores)[::-1][:K2].tolist()), set(np.argsort(oscores)[::-1][:K2].tolist())
+    parity("trim_input_hist_secondary: final 32 not in the oracle's 32", len(top_dev - top_orc), 2)
+    assert int(np.argmax(scores)) == int(np.argmax(oscores))
+    # ---- and the composed call
+    it, ir = utils.make_input(img, X, C, K2, init, "loss_histogram", K1)
+    assert it.shape == (K2, 3) and ir.shape == (K2, 3)
+    order = np.argsort(-scores, kind="stable")[:K2]
+    assert np.array_equal(it.cpu().numpy(), t1.cpu().numpy()[order]) or len(top_dev) == K2
+    R_gt = synth.rot_from_ypr_np(ypr_gt)
+    errs = [synth.pose_errors(it[i].cpu().numpy(), synth.rot_from_ypr_np(ir[i].cpu().numpy()), t_gt, R_gt) for i in range(K2)]
+    assert min(e[0] for e in errs) < 1.5                        # the grid pose next to the truth survives both trims
