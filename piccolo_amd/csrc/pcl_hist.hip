@@ -125,6 +125,8 @@ struct PclBinArgs {
     int64_t n, stride;
     const PclPoseRec* poses;
     int H, W, ntx, nt;                 // tiles per row, tiles per image
+    int ty_lo, ty_hi;                  // tile rows that hold pixels of the scored block rows 1 .. nsh-2 (utils.py:556): the
+                                       // tiles above and below are never binned — half the image at num_split_h = 4
     int* counts;                       // [ncand][nt]      points (with multiplicity) per tile
     int* offsets;                      // [ncand][nt + 1]  exclusive scan of counts
     int* cursors;                      // [ncand][nt]      scatter cursors
@@ -145,14 +147,16 @@ __device__ __forceinline__ void pcl_bin_project(const PclBinArgs& a, const PclPo
 }
 
 // the (up to four) tiles a 3 x 3 splat centred on (row, col) touches, after the clamp to the image
-__device__ __forceinline__ int pcl_bin_tiles(int row, int col, int H, int W, int ntx, int tiles[4])
+__device__ __forceinline__ int pcl_bin_tiles(int row, int col, int H, int W, int ntx, int ty_lo, int ty_hi, int tiles[4])
 {
     int ra = max(row - 1, 0) >> PCL_TS_SHIFT, rb = min(row + 1, H - 1) >> PCL_TS_SHIFT;
     int ca = max(col - 1, 0) >> PCL_TS_SHIFT, cb = min(col + 1, W - 1) >> PCL_TS_SHIFT;
     int k = 0;
-    tiles[k++] = ra * ntx + ca;
-    if (cb != ca) tiles[k++] = ra * ntx + cb;
-    if (rb != ra) {
+    if (ra >= ty_lo && ra <= ty_hi) {
+        tiles[k++] = ra * ntx + ca;
+        if (cb != ca) tiles[k++] = ra * ntx + cb;
+    }
+    if (rb != ra && rb >= ty_lo && rb <= ty_hi) {
         tiles[k++] = rb * ntx + ca;
         if (cb != ca) tiles[k++] = rb * ntx + cb;
     }
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
             int row, col;
             float d;
             pcl_bin_project(a, a.poses + cand, i, row, col, d);
-            ntl[k] = pcl_bin_tiles(row, col, a.H, a.W, a.ntx, tiles[k]);
+            ntl[k] = pcl_bin_tiles(row, col, a.H, a.W, a.ntx, a.ty_lo, a.ty_hi, tiles[k]);
             pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
             dep[k] = __float_as_uint(d);
             for (int j = 0; j < ntl[k]; j++) atomicAdd(&cnt[tiles[k][j]], 1);
@@ -265,45 +269,87 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_scan_kernel(PclBinArgs a)
 // overlaps; tiny blocks — more than that per tile — go to the global counters directly).
 // (1024 threads: the heaviest tile of a candidate — up to 20x the mean — sets the duration of the launch)
 #define PCL_RESOLVE_THREADS 1024
+#ifdef PCL_BLOCK_TRACE                                 // experiments: tools/block_trace.py-style end stamps (see pcl_loss.hip)
+__device__ unsigned long long* pcl_hist_trace_buf = nullptr;
+extern "C" int pcl_debug_set_hist_trace(unsigned long long* buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcl_hist_trace_buf), &buf, sizeof(buf));
+}
+#endif
 __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, const float* __restrict__ img, int nsh, int nsw,
                                                                           unsigned int* __restrict__ ghist)
 {
-    __shared__ unsigned long long tile[PCL_TS * PCL_TS];
+    // the tile with a halo of two pixels: every splat pixel of every listed entry has a cell (an entry is listed when its 3 x 3
+    // splat touches the tile, so its centre is at most one pixel outside), and the nine writes need no membership test
+    constexpr int TW = PCL_TS + 4;
+    __shared__ unsigned long long tile[TW * TW];
     __shared__ unsigned int hist[4][PCL_HBINS];
-    const int cand = blockIdx.y;
-    const int t = a.order[(int64_t)cand * a.nt + blockIdx.x];          // heaviest tiles first
+    // candidate fastest: workgroups are handed out x first, so rank 0 — the heaviest tile — of EVERY candidate starts before
+    // any rank-1 tile (tile-major launches started the last candidate's heaviest tile at 94 % of the launch)
+    const int cand = blockIdx.x;
+    const int t = a.order[(int64_t)cand * a.nt + blockIdx.y];          // heaviest tiles first
+#ifdef PCL_BLOCK_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
     const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
     const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
-    for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
-    for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
-    __syncthreads();
     const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
     const uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
     const int e0 = off[t], e1 = off[t + 1];
-    for (int e = e0 + threadIdx.x; e < e1; e += PCL_RESOLVE_THREADS) {
-        const uint32_t pix = list[e], dbits = list[a.cap + e], i = list[2 * a.cap + e];
-        const int row = (int)(pix >> 16), col = (int)(pix & 0xffffu);
-        const unsigned long long bk = ((unsigned long long)dbits << 29) | (unsigned long long)(0x1fffffffu - i);
+    if (e0 == e1) return;                              // nothing projects here (or the tile is outside the scored rows)
+    const int r_org = ty * PCL_TS - 2, c_org = tx * PCL_TS - 2;
+    for (int i = threadIdx.x; i < TW * TW; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
+    for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    // four entries in flight per lane (the lists of the heavy tiles — up to 68k entries at 1M points, 30x the mean — are
+    // walked by one workgroup)
+    constexpr int UNR = 4;
+    for (int e = e0 + threadIdx.x; e < e1; e += UNR * PCL_RESOLVE_THREADS) {
+        uint32_t pixv[UNR], depv[UNR], idv[UNR];
 #pragma unroll
-        for (int p = 0; p < 9; p++) {
-            int r = min(max(row + drow[p], 0), a.H - 1), c = min(max(col + dcol[p], 0), a.W - 1);
-            if ((r >> PCL_TS_SHIFT) == ty && (c >> PCL_TS_SHIFT) == tx) {
-                // a plain read first: cells only ever decrease, so a key that does not beat what is already there can be
-                // dropped without the atomic (in the dense tiles — a far wall seen from the other end of the room puts
-                // 40k points into one tile, 20x the mean — almost every key loses)
-                unsigned long long* cell = &tile[(r & (PCL_TS - 1)) * PCL_TS + (c & (PCL_TS - 1))];
+        for (int u = 0; u < UNR; u++) {
+            const int eu = e + u * PCL_RESOLVE_THREADS;
+            const bool ok = eu < e1;
+            pixv[u] = ok ? list[eu] : 0xffffffffu;
+            depv[u] = ok ? list[a.cap + eu] : 0u;
+            idv[u] = ok ? list[2 * a.cap + eu] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (pixv[u] == 0xffffffffu) continue;
+            const uint32_t pix = pixv[u], dbits = depv[u], i = idv[u];
+            const int row = (int)(pix >> 16), col = (int)(pix & 0xffffu);
+            const unsigned long long bk = ((unsigned long long)dbits << 29) | (unsigned long long)(0x1fffffffu - i);
+            // clamped at the image border as the reference's index arithmetic is (utils.py:173-198), then tile-local
+            const int r3[3] = {(max(row - 1, 0) - r_org) * TW, (row - r_org) * TW, (min(row + 1, a.H - 1) - r_org) * TW};
+            const int c3[3] = {max(col - 1, 0) - c_org, col - c_org, min(col + 1, a.W - 1) - c_org};
+            // A plain read first: cells only ever decrease, so a key that does not beat what is already there can be dropped
+            // without the atomic (in the dense tiles — a far wall seen from the other end of the room — almost every key
+            // loses).  All nine reads are issued before the first compare: one LDS round trip per entry instead of nine
+            // (a stale value only costs an atomic that loses).
+            unsigned long long cur[9];
+#pragma unroll
+            // (relaxed atomic loads, not volatile ones: a volatile read of LDS compiles to a system-coherent FLAT load with a
+            // full wait behind it — nine serial round trips through the memory pipeline per entry, which was 80 % of this kernel)
+            for (int p = 0; p < 9; p++)
+                cur[p] = __hip_atomic_load(&tile[r3[drow[p] + 1] + c3[dcol[p] + 1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int p = 0; p < 9; p++) {
                 const unsigned long long key = ((unsigned long long)(8 - p) << 60) | bk;
-                if (key < *(volatile unsigned long long*)cell) atomicMin(cell, key);
+                if (key < cur[p]) atomicMin(&tile[r3[drow[p] + 1] + c3[dcol[p] + 1]], key);
             }
         }
     }
     __syncthreads();
+#ifdef PCL_BLOCK_TRACE
+    const unsigned long long trace_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int bh = a.H / nsh, bw = a.W / nsw, nblk = (nsh - 2) * nsw;
     const int h_lo = (ty * PCL_TS) / bh, w_lo = (tx * PCL_TS) / bw;       // first histogram block row / column of this tile
     unsigned int* g = ghist + (int64_t)cand * nblk * PCL_HBINS;
     for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) {
-        const unsigned long long k = tile[i];
+        const unsigned long long k = tile[((i >> PCL_TS_SHIFT) + 2) * TW + (i & (PCL_TS - 1)) + 2];
         const int r = ty * PCL_TS + (i >> PCL_TS_SHIFT), c = tx * PCL_TS + (i & (PCL_TS - 1));
         if (k == ~0ull || r >= a.H || c >= a.W) continue;
         const int h = r / bh, w = c / bw;
@@ -321,6 +367,9 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
         else atomicAdd(&g[(int64_t)blk * PCL_HBINS + code], 1u);
     }
     __syncthreads();
+#ifdef PCL_BLOCK_TRACE
+    const unsigned long long trace_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) {
         const unsigned int v = (&hist[0][0])[i];
         if (!v) continue;
@@ -329,6 +378,16 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
         if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // (cannot hold counts: guarded when accumulated)
         atomicAdd(&g[(int64_t)((h - 1) * nsw + w) * PCL_HBINS + code], v);
     }
+#ifdef PCL_BLOCK_TRACE
+    if (pcl_hist_trace_buf && threadIdx.x == 0) {
+        unsigned long long* tb = pcl_hist_trace_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5;
+        tb[0] = __builtin_amdgcn_s_memrealtime();
+        tb[1] = (unsigned long long)(e1 - e0);
+        tb[2] = trace_t0;
+        tb[3] = trace_t1;
+        tb[4] = trace_t2;
+    }
+#endif
 }
 
 
@@ -500,12 +559,14 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
         b.order = b.cursors + (int64_t)ncand * nt;
         b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
         b.cap = cap;
+        const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
+        b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
         (void)hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
         dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
         hipLaunchKernelGGL(pcl_bin_kernel<false>, pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
         hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
         hipLaunchKernelGGL(pcl_bin_kernel<true>, pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
-        hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel, dim3(nt, ncand), dim3(PCL_RESOLVE_THREADS), 0, s, b, img_hwc, nsh, nsw, ghist_c);
+        hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel, dim3(ncand, nt), dim3(PCL_RESOLVE_THREADS), 0, s, b, img_hwc, nsh, nsw, ghist_c);
     } else {
         hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
         // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
