@@ -147,20 +147,17 @@ __device__ __forceinline__ void pcl_bin_project(const PclBinArgs& a, const PclPo
 }
 
 // the (up to four) tiles a 3 x 3 splat centred on (row, col) touches, after the clamp to the image
-__device__ __forceinline__ int pcl_bin_tiles(int row, int col, int H, int W, int ntx, int ty_lo, int ty_hi, int tiles[4])
+__device__ __forceinline__ void pcl_bin_tiles(int row, int col, int H, int W, int ntx, int ty_lo, int ty_hi, int tiles[4])
 {
+    // the up to four tiles the 3 x 3 splat of pixel (row, col) touches, -1 for the absent ones: four fixed slots, so that the
+    // callers index them with compile-time constants (a count + a runtime-indexed array put the array in scratch memory)
     int ra = max(row - 1, 0) >> PCL_TS_SHIFT, rb = min(row + 1, H - 1) >> PCL_TS_SHIFT;
     int ca = max(col - 1, 0) >> PCL_TS_SHIFT, cb = min(col + 1, W - 1) >> PCL_TS_SHIFT;
-    int k = 0;
-    if (ra >= ty_lo && ra <= ty_hi) {
-        tiles[k++] = ra * ntx + ca;
-        if (cb != ca) tiles[k++] = ra * ntx + cb;
-    }
-    if (rb != ra && rb >= ty_lo && rb <= ty_hi) {
-        tiles[k++] = rb * ntx + ca;
-        if (cb != ca) tiles[k++] = rb * ntx + cb;
-    }
-    return k;
+    const bool top = ra >= ty_lo && ra <= ty_hi, bot = rb != ra && rb >= ty_lo && rb <= ty_hi, two = cb != ca;
+    tiles[0] = top ? ra * ntx + ca : -1;
+    tiles[1] = top && two ? ra * ntx + cb : -1;
+    tiles[2] = bot ? rb * ntx + ca : -1;
+    tiles[3] = bot && two ? rb * ntx + cb : -1;
 }
 
 // SCATTER = false: count; true: reserve a range per (block, tile) and write the entries.  A block takes PCL_BIN_PTS
@@ -179,20 +176,23 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cnt[t] = 0;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
-    int tiles[PER][4], ntl[PER];
+    int tiles[PER][4];
     uint32_t pix[PER], dep[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int64_t i = first + (int64_t)k * PCL_BLOCK;
-        ntl[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) tiles[k][j] = -1;
         if (i < a.n) {
             int row, col;
             float d;
             pcl_bin_project(a, a.poses + cand, i, row, col, d);
-            ntl[k] = pcl_bin_tiles(row, col, a.H, a.W, a.ntx, a.ty_lo, a.ty_hi, tiles[k]);
+            pcl_bin_tiles(row, col, a.H, a.W, a.ntx, a.ty_lo, a.ty_hi, tiles[k]);
             pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
             dep[k] = __float_as_uint(d);
-            for (int j = 0; j < ntl[k]; j++) atomicAdd(&cnt[tiles[k][j]], 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (tiles[k][j] >= 0) atomicAdd(&cnt[tiles[k][j]], 1);
         }
     }
     __syncthreads();
@@ -214,8 +214,10 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int64_t i = first + (int64_t)k * PCL_BLOCK;
-        for (int j = 0; j < ntl[k]; j++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
             const int t = tiles[k][j];
+            if (t < 0) continue;
             const int pos = off[t] + base[t] + atomicAdd(&cnt[t], 1);
             // the projection travels with the entry: the resolve kernel reads 12 coalesced bytes per entry instead of chasing
             // slot -> x, y, z and projecting a third time
