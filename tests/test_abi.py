@@ -98,3 +98,39 @@ def test_product_never_imports_the_oracle():
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
     assert "oracle" not in open(os.path.join(REPO, "main.py")).read()
+
+
+def test_every_entry_point_rejects_null_arguments_before_touching_a_device():
+    """Error behaviour of the whole boundary: every status-returning function called with null pointers and zero sizes
+    answers PCL_EINVAL (-1) — no crash, no HIP call (this runs without a GPU) — and every *_bytes sizing function answers 0
+    for an empty problem."""
+    import ctypes
+    from piccolo_amd import _lib
+    lib = _lib.load()
+    skipped, wrong = [], []
+    for name, (res, args) in sorted(_lib.SIGNATURES.items()):
+        if name in ("pcl_abi_version", "pcl_error_string", "pcl_color_workspace_bytes", "pcl_quantile_workspace_bytes"):
+            continue                                        # no arguments to get wrong / constant
+        zero = []
+        for a in args:
+            if a in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(a, "contents"):
+                zero.append(None)
+            elif a in (ctypes.c_float, ctypes.c_double):
+                zero.append(0.0)
+            else:
+                zero.append(0)
+        rc = getattr(lib, name)(*zero)
+        if res is ctypes.c_int:
+            if rc != -1:
+                wrong.append((name, rc))
+        elif res is ctypes.c_size_t:
+            if rc != 0:
+                wrong.append((name, rc))
+        elif res is ctypes.c_int64:
+            if rc > 0:                                      # cloud_stride(0) = 0; text readers: negative status
+                wrong.append((name, rc))
+        else:
+            skipped.append(name)
+    assert not wrong, wrong
+    # handle-returning / void functions: called with nulls above without a crash, nothing to compare
+    assert set(skipped) <= {"pcl_timer_create", "pcl_timer_destroy", "pcl_timer_reset", "pcl_timer_set_stride"}, skipped
