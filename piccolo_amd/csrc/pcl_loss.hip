@@ -37,6 +37,7 @@ struct PclLossArgs {
     float* partials;         // [nchunks][B][8]
     int nchunks;             // multiple of 8
     int ngroups;             // B / G
+    int seg_len;                 // chunks per contiguous run of one XCD (see the mapping at the top of pcl_loss_kernel)
     int steps_base, steps_rem;   // the cloud's ceil(n / PCL_STEP) steps are dealt out evenly: chunk c has steps_base + (c < steps_rem)
 };
 
@@ -367,14 +368,19 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
 template <int G, bool GRAD, bool VIS, int FMT>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
 {
-    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.
-    // Give every XCD a contiguous range of CHUNKS (a compact part of the room, hence of the panorama for all the
-    // nearby candidate poses) and let the pose group vary fastest, so the blocks that are resident together on an XCD
-    // read the same cloud chunk and neighbouring texels: both stay in that XCD's L2 across the pose groups.
-    const int nblk = gridDim.x;                       // = nchunks * ngroups, multiple of 8
-    const int per_xcd = nblk >> 3;
-    const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int chunk = v / a.ngroups, group = v - chunk * a.ngroups;
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.  Within an
+    // XCD the pose group varies fastest, so the blocks that are resident together read the same cloud chunk (it stays in
+    // that XCD's L2 across the pose groups) and, the candidates being near each other, neighbouring texels.
+    // Which chunks an XCD gets: chunk c belongs to XCD c mod 8 (seg_len = 1).  Round 1 gave every XCD ONE contiguous range of
+    // chunks, i.e. its own eighth of the room — and the eighths differ in cost (how many points leave the panorama's valid
+    // rows, how well their texels cache): tools/block_trace.py showed one to three XCDs done 10-30 % before the others in
+    // every launch and idle through the tail, since the dispatcher deals blocks to XCDs round-robin whatever their speed.
+    // Measured at cfg 2, one image per launch chain (bench.py single_image, same box): 1 / 2 / 4 / 8 / 32 runs per XCD
+    // 2802 / 2832 / 2889 / 2933 / 2988 candidate-poses/s, and 3047 with every chunk its own run (frac 0.86 -> 0.93);
+    // 8 images per launch +0.7 %, cfg 5 +2.4 %; the 1800-pose forward launch is unchanged.
+    const int lc = (int)(blockIdx.x >> 3) / a.ngroups, group = (int)(blockIdx.x >> 3) - lc * a.ngroups;   // chunk within the XCD
+    const int run = lc / a.seg_len;
+    const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lc - run * a.seg_len);
     const int pose0 = group * G;
 
     __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
@@ -508,6 +514,7 @@ static int pcl_env_int(const char* name, int dflt)
 
 struct PclPlan {
     int G, ngroups, nchunks;
+    int seg_len;
     int steps_base, steps_rem;
 };
 
@@ -530,6 +537,12 @@ static PclPlan pcl_plan(int64_t n, int B)
     p.nchunks = (int)want;
     p.steps_base = (int)(steps / want);
     p.steps_rem = (int)(steps % want);
+    // contiguous chunk runs per XCD (PCL_XCD_RUNS, experiments; default: every chunk its own run, chunk c on XCD c mod 8):
+    // the largest divisor of the XCD's chunk count not above the target
+    static const int runs_env = pcl_env_int("PCL_XCD_RUNS", 0);
+    int cpx = p.nchunks / 8, runs = runs_env < 1 || runs_env > cpx ? cpx : runs_env;
+    while (cpx % runs) runs--;
+    p.seg_len = cpx / runs;
     return p;
 }
 
@@ -573,7 +586,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
-    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
+    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
     if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
