@@ -5,10 +5,12 @@
 // parameters (omniloc.py:260-263) and the clamp to the quantile box (omniloc.py:52-58, :265-269).
 // One 256-thread block per candidate pose (four waves gather the partial sums, wave 0 runs the optimiser update in the
 // same precision mix as the reference: fp32 tensors, python-double scalars).
+#include <stdlib.h>
+
 #include "pcl_gd_device.h"
 
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s);
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip);
 size_t pcl_partials_bytes(int64_t n, int B);
 int pcl_plan_nchunks(int64_t n, int B);
 size_t pcl_depth_zbuf_bytes(int B, int H, int W);
@@ -69,7 +71,7 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano
     float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
     hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
     PCL_LAUNCH_CHECK();
-    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s);
+    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s, 0);
     if (rc) return rc;
     hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
                        with_grad, result);
@@ -211,6 +213,10 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         visible = (uint8_t*)zbuf + gd_align(pcl_depth_zbuf_bytes(B, H, W));
     }
     const int nchunks = pcl_plan_nchunks(n, B);
+    // odd iterations walk every XCD's chunks backwards: the first blocks of a launch then read the chunks the previous launch
+    // finished with, still in that XCD's L2 (PCL_FLIP=0 turns it off; +0.3 % at cfg 2 in two A/B alternations on one box —
+    // the first round of a launch stays 6 us slower than the later ones, so cold L2 is not what makes it slow)
+    static const int flip_env = getenv("PCL_FLIP") ? atoi(getenv("PCL_FLIP")) : 1;
     for (int it = 0; it < num_iter; it++) {
         if (visible) {
             int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, s);
@@ -223,7 +229,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             hipError_t e = hipEventRecord(tm->start[tm->used], s);
             if (e != hipSuccess) return (int)e;
         }
-        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s);
+        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s, flip_env ? (it & 1) : 0);
         if (rc) return rc;
         if (timed) {
             // (only a completed start/stop pair counts as used: pcl_timer_read never sees a half-recorded slot)

@@ -37,6 +37,7 @@ struct PclLossArgs {
     float* partials;         // [nchunks][B][8]
     int nchunks;             // multiple of 8
     int ngroups;             // B / G
+    int flip;                    // 1: every XCD walks its chunks from the last to the first (see pcl_launch_loss)
     int seg_len;                 // chunks per contiguous run of one XCD (see the mapping at the top of pcl_loss_kernel)
     int steps_base, steps_rem;   // the cloud's ceil(n / PCL_STEP) steps are dealt out evenly: chunk c has steps_base + (c < steps_rem)
 };
@@ -378,7 +379,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
     // Measured at cfg 2, one image per launch chain (bench.py single_image, same box): 1 / 2 / 4 / 8 / 32 runs per XCD
     // 2802 / 2832 / 2889 / 2933 / 2988 candidate-poses/s, and 3047 with every chunk its own run (frac 0.86 -> 0.93);
     // 8 images per launch +0.7 %, cfg 5 +2.4 %; the 1800-pose forward launch is unchanged.
-    const int lc = (int)(blockIdx.x >> 3) / a.ngroups, group = (int)(blockIdx.x >> 3) - lc * a.ngroups;   // chunk within the XCD
+    const int lq = (int)(blockIdx.x >> 3) / a.ngroups, group = (int)(blockIdx.x >> 3) - lq * a.ngroups;
+    const int lc = a.flip ? (a.nchunks >> 3) - 1 - lq : lq;                                             // chunk within the XCD
     const int run = lc / a.seg_len;
     const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lc - run * a.seg_len);
     const int pose0 = group * G;
@@ -576,7 +578,7 @@ static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, bool 
 
 // Enqueue one fused loss(+grad) pass over the cloud for B poses; partials must hold pcl_partials_bytes(n, B).
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s)
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip)
 {
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
@@ -586,7 +588,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
-    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
+    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.flip = flip; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
     if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
