@@ -539,10 +539,14 @@ static PclPlan pcl_plan(int64_t n, int B)
     p.nchunks = (int)want;
     p.steps_base = (int)(steps / want);
     p.steps_rem = (int)(steps % want);
-    // contiguous chunk runs per XCD (PCL_XCD_RUNS, experiments; default: every chunk its own run, chunk c on XCD c mod 8):
-    // the largest divisor of the XCD's chunk count not above the target
+    // contiguous chunk runs per XCD (PCL_XCD_RUNS, experiments).  Default: every chunk its own run (chunk c on XCD c mod 8)
+    // when the launch takes several rounds of resident blocks — the XCDs then finish together; ONE run per XCD when all blocks
+    // are resident at once (the shipped 167k-point / 6-candidate shape: 984 one-step blocks): nothing to balance there, and
+    // with its chunks side by side an XCD touches an eighth of the panorama instead of all of it (loss kernel 9.5 vs 10.8 us).
+    // Otherwise the largest divisor of the XCD's chunk count not above the target.
     static const int runs_env = pcl_env_int("PCL_XCD_RUNS", 0);
     int cpx = p.nchunks / 8, runs = runs_env < 1 || runs_env > cpx ? cpx : runs_env;
+    if (runs_env < 1 && (int64_t)p.nchunks * p.ngroups <= 1024) runs = 1;       // 256 CUs x 4 resident 256-thread blocks
     while (cpx % runs) runs--;
     p.seg_len = cpx / runs;
     return p;

@@ -6,7 +6,7 @@ ROOF_KEY=cfg2/poses256/f16 POINT_POSES=256e6 ROOF_SOURCE=$R/a_default_cfg2_8imag
   bash profiles/collect.sh ${R}_a --workload cfg2 $PMC
 ROOF_KEY=cfg2/poses32/f16 POINT_POSES=32e6 ROOF_SOURCE=$R/b_cfg2_single_image ROOF_CMD="bench.py --images-per-launch 1" \
   bash profiles/collect.sh ${R}_b --workload cfg2 --images-per-launch 1 $PMC
-ROOF_KEY=cfg5/poses128/f16 POINT_POSES=1280e6 ROOF_SOURCE=$R/c_cfg5 ROOF_CMD="bench.py --workload cfg5 --steps 4" \
+ROOF_KEY=cfg5/poses64/f16 POINT_POSES=640e6 ROOF_SOURCE=$R/c2_cfg5_2images ROOF_CMD="bench.py --workload cfg5 --steps 4" \
   bash profiles/collect.sh ${R}_c --workload cfg5 --steps 4 --warmup 1 --no-cpu-baseline
 ROOF_KEY=cfg3/poses256/f16 POINT_POSES=256e6 ROOF_SOURCE=$R/d_cfg3 ROOF_CMD="bench.py --workload cfg3 --steps 2" \
   bash profiles/collect.sh ${R}_d --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline
