@@ -82,6 +82,12 @@ __device__ __forceinline__ f2 pcl_atan_poly2(f2 t)
 }
 
 // first-octant angle atan(min/max) of two magnitudes (packed) and the "second is larger" flags
+// (Measured and rejected, round 2: asin(min * rs) with rs = v_rsq(u^2 + v^2), the same rs squared serving the gradient's
+// 1/(u^2 + v^2) — four transcendentals per point-pose instead of six (each occupies the VALU for two issue slots), same
+// polynomial length: 3 393 -> 3 493 candidate-poses/s at cfg 2 (+3 %).  But asin amplifies the rounding of its argument by up
+// to sqrt 2 where atan damps it by up to 2, and the argument carries the rounding of the sum of squares as well: the sample
+// positions get about twice the noise, and G3's grad_t moved from 6.9e-7 to 1.7e-6 of the reference's fp64 autograd (the
+// reference's own fp32 run: 3.5e-6), with or without a Newton step on rs^2.  Parity before 3 %.)
 // (the min as one VOP3 with |.| modifiers, in asm: for operands that come out of the rotation's asm block the compiler
 // cannot prove them canonical and would put a v_max x,x in front of every fminf)
 __device__ __forceinline__ float pcl_min_abs(float a, float b)
