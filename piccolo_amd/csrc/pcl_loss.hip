@@ -83,7 +83,7 @@ __device__ __forceinline__ f2 pcl_atan_poly2(f2 t)
 
 // first-octant angle atan(min/max) of two magnitudes (packed) and the "second is larger" flags
 // (Measured and rejected, round 2: asin(min * rs) with rs = v_rsq(u^2 + v^2), the same rs squared serving the gradient's
-// 1/(u^2 + v^2) — four transcendentals per point-pose instead of six (each occupies the VALU for two issue slots), same
+// 1/(u^2 + v^2) — four transcendentals per point-pose instead of six (they issue at a fraction of the plain rate), same
 // polynomial length: 3 393 -> 3 493 candidate-poses/s at cfg 2 (+3 %).  But asin amplifies the rounding of its argument by up
 // to sqrt 2 where atan damps it by up to 2, and the argument carries the rounding of the sum of squares as well: the sample
 // positions get about twice the noise, and G3's grad_t moved from 6.9e-7 to 1.7e-6 of the reference's fp64 autograd (the
