@@ -19,7 +19,8 @@ The JSON line carries both launch modes and both roofs:
                               rocprofv3 PMC passes of THIS launch shape (profiles/roofs.json), null for any other shape;
     roofline.hbm_measured     those measured bytes over the measured kernel time: the bandwidth the kernel really draws
     roofline.valu             the roof that actually binds (the cloud and the panorama are cache resident): VALU instructions
-                              per point-pose and the VALU-busy fraction, from the same PMC passes
+                              per point-pose and the VALU-busy fraction, from the same PMC passes; issue_frac_live = those
+                              instructions over this run's launch time against 1 instruction / SIMD / 4 cycles at 2400 MHz
 """
 import argparse
 import json
@@ -364,7 +365,15 @@ def main():
                                     "shape over this run's kernel time: the cloud and the panorama are cache resident, HBM is idle"}
         valu = None
         if roofs and roofs.get("valu_instr_per_point_pose"):
+            # live VALU-issue figure: this run's kernel time against one wave64 VALU instruction per SIMD every 4 cycles
+            # at the guide's 2400 MHz maximum clock (256 CUs x 4 SIMDs) — counted instructions only: transcendentals,
+            # s_nop slots between dependent packed ops and clocks below the maximum all lower it
+            wave_instr = roofs["valu_instr_per_point_pose"] * N * B * len(groups[0]) / 64.0
+            issue_peak = 1024 * 2.4e9 / 4.0 * (per_launch_ms * 1e-3)
             valu = {"instr_per_point_pose": roofs["valu_instr_per_point_pose"], "busy_frac": roofs["valu_busy_frac"],
+                    "issue_frac_live": wave_instr / issue_peak,
+                    "issue_frac_is": "profiled wave64 VALU instructions per launch / (1024 SIMDs x 2400 MHz / 4 cycles x this run's "
+                                     "average launch time)",
                     "source": roofs.get("source"),
                     "note": "wave64 VALU instructions per 64 point-poses and 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): "
                             "the kernel is VALU-issue bound, this is the roof with headroom left"}
