@@ -383,3 +383,38 @@ def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
             assert float(out["0"][0].abs().sum()) > 0
     finally:
         os.environ.pop("PCL_HIST_SPLAT", None)
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_the_block_to_xcd_mapping():
+    """Which XCD evaluates which chunk, and in which order (contiguous ranges, interleaved chunks, odd iterations walking
+    backwards), is scheduling only: every chunk's partial sums land in its own slot and the second-stage sum runs over the
+    slots in index order, so a multi-round refinement must come out bit for bit the same under every mapping.  The knobs are
+    read once per process: one child process per setting."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = (
+        "import hashlib, numpy as np, torch\n"
+        "from piccolo_amd import ops, synth\n"
+        "n, H, W, B = 300_000, 256, 512, 8\n"
+        "xyz, rgb = synth.box_room(n, 5)\n"
+        "X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()\n"
+        "t_gt, ypr_gt = synth.gt_pose(5)\n"
+        "img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))\n"
+        "tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=5)\n"
+        "cloud, pano = ops.Cloud(X, C), ops.Pano(img)\n"
+        "assert ops._lib.load().pcl_loss_workspace_bytes(n, B) // (B * 32) * (B // 2) > 1024      # chunks x groups: several rounds\n"
+        "gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr).cuda(), torch.from_numpy(ro).cuda(), ops.quantile_box(X, 0.05), lr=0.1, factor=0.9, patience=5)\n"
+        "gd.run(25)\n"
+        "print(hashlib.sha256(gd.result().cpu().numpy().tobytes()).hexdigest())\n")
+    digests = {}
+    for runs, flip in (("0", "1"), ("1", "0"), ("4", "1"), ("0", "0")):
+        env = dict(os.environ, PCL_XCD_RUNS=runs, PCL_FLIP=flip)
+        out = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[(runs, flip)] = out.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
+    assert len(hashlib.sha256(b"").hexdigest()) == len(next(iter(digests.values())))
