@@ -29,6 +29,10 @@ extern "C" {
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
 
+/* largest cloud of the loss / refinement / ordering entry points: the six planes of the packed cloud are addressed through one
+ * 32-bit buffer descriptor (6 x 4 B x n < 4 GiB); a larger n is answered with PCL_EINVAL before anything is enqueued */
+#define PCL_MAX_POINTS ((int64_t)1 << 27)
+
 /* number of floats per pose in result blocks: loss, count, dL/dt[3], dL/dyaw, dL/dpitch, dL/droll */
 #define PCL_RESULT_STRIDE 8
 

@@ -62,7 +62,7 @@ extern "C" size_t pcl_color_template_workspace_bytes(int64_t n)
 
 extern "C" int pcl_color_template_build(const float* rgb, int64_t n, float* tmpl, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!rgb || !tmpl || !workspace || n <= 0 || n > ((int64_t)1 << 27)) return PCL_EINVAL;
+    if (!rgb || !tmpl || !workspace || n <= 0 || n > PCL_MAX_POINTS) return PCL_EINVAL;
     if (workspace_bytes < pcl_color_template_workspace_bytes(n)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* planes = (float*)workspace;
@@ -228,7 +228,7 @@ extern "C" size_t pcl_color_workspace_bytes(void) { return color_align(sizeof(Pc
 extern "C" int pcl_color_match(const float* img, int H, int W, const float* tmpl, int64_t n, float* out, int32_t* not_exact,
                                void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!img || !tmpl || !out || !workspace || H <= 0 || W <= 0 || n <= 0 || n > ((int64_t)1 << 27)) return PCL_EINVAL;
+    if (!img || !tmpl || !out || !workspace || H <= 0 || W <= 0 || n <= 0 || n > PCL_MAX_POINTS) return PCL_EINVAL;
     if (workspace_bytes < pcl_color_workspace_bytes()) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     PclColorHist* hist = (PclColorHist*)workspace;

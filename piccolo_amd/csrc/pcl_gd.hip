@@ -65,6 +65,7 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano
                                  void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!cloud || !pano || !trans || !rot || !result || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (n > PCL_MAX_POINTS) return PCL_EINVAL;               // (before anything is enqueued)
     if (workspace_bytes < pcl_loss_workspace_bytes(n, B)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     PclPoseRec* recs = (PclPoseRec*)workspace;
@@ -201,6 +202,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     PclTimer* tm = (PclTimer*)timer;
     if (!cloud || !pano || !state || !box || !hyper_host || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0 || num_iter < 0)
         return PCL_EINVAL;
+    if (n > PCL_MAX_POINTS) return PCL_EINVAL;
     if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
     if (workspace_bytes < pcl_gd_workspace_bytes(n, B, H, W, hyper_host)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;

@@ -592,7 +592,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
 {
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
-    if (n > (int64_t)1 << 27 || (int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
+    if (n > PCL_MAX_POINTS || (int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
     PclPlan p = pcl_plan(n, B);
     PclLossArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);

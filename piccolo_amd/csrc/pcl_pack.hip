@@ -157,7 +157,7 @@ extern "C" size_t pcl_cloud_order_workspace_bytes(int64_t n)
 // pcl_cloud_pack.  Equal keys keep their original relative order (stable LSD radix sort).
 extern "C" int pcl_cloud_order(const float* xyz, int64_t n, int64_t* order, void* workspace, size_t workspace_bytes, void* stream)
 {
-    if (!xyz || !order || !workspace || n <= 0 || n > ((int64_t)1 << 27)) return PCL_EINVAL;
+    if (!xyz || !order || !workspace || n <= 0 || n > PCL_MAX_POINTS) return PCL_EINVAL;
     if (workspace_bytes < pcl_cloud_order_workspace_bytes(n)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;

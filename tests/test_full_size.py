@@ -187,3 +187,40 @@ def test_full_size_initialisation_stage_vs_oracle(ops, oracle, parity):
     R_gt = synth.rot_from_ypr_np(ypr_gt)
     errs = [synth.pose_errors(it[i].cpu().numpy(), synth.rot_from_ypr_np(ir[i].cpu().numpy()), t_gt, R_gt) for i in range(K2)]
     assert min(e[0] for e in errs) < 1.5                        # the grid pose next to the truth survives both trims
+
+
+def test_maximum_cloud_size_vs_oracle(ops, oracle, parity):
+    """The largest cloud the ABI accepts: n = 2^27 points (the packed cloud's six planes are addressed through one 32-bit
+    buffer descriptor: 6 x 4 B x n < 4 GiB, so the last plane's offsets lie above 2^31).  Loss, count and gradient of two
+    poses against the fp64 oracle over all 134M points; one point more is refused."""
+    import ctypes
+    from piccolo_amd import _lib, synth
+    n, H, W, B = 1 << 27, 256, 512, 2
+    base_xyz, base_rgb = synth.box_room(1 << 20, 7)
+    # 128 copies of a 1M-point room, each shifted by a few tenths of a millimetre (all distinct points, same room)
+    k = np.arange(128, dtype=np.float32)
+    shift = np.stack([1e-4 * (k % 5), 1e-4 * ((k // 5) % 5), 1e-4 * (k // 25)], 1)
+    xyz = (base_xyz[None, :, :] + shift[:, None, :]).reshape(-1, 3).astype(np.float32)
+    rgb = np.broadcast_to(base_rgb[None, :, :], (128,) + base_rgb.shape).reshape(-1, 3).copy()
+    assert xyz.shape[0] == n
+    X, C = T(xyz), T(rgb)
+    t_gt, ypr_gt = synth.gt_pose(7)
+    Xs, Cs = T(base_xyz), T(base_rgb)
+    img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(Xs, T(t_gt), T(ypr_gt)), Cs, (H, W)))
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=7)
+    cloud = ops.Cloud(X, C)                                           # Morton order + pack at the limit
+    assert cloud.n == n
+    out = ops.sampling_loss(cloud, ops.Pano(img), T(trans), T(rot), with_grad=True).cpu().numpy()
+    del X, C, cloud
+    torch.cuda.empty_cache()
+    r64, r32 = _oracle_pair(oracle, xyz, rgb, img.cpu().numpy(), trans, rot)
+    _check_vs_oracle(parity, out, r64, r32, n, "n = 2^27: ")
+    # one point more: refused before anything is launched (status, no exception from the device)
+    lib = _lib.load()
+    dummy = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    rc = lib.pcl_sampling_loss(ctypes.c_void_p(dummy.data_ptr()), n + 1, ctypes.c_void_p(dummy.data_ptr()), 0, H, W,
+                               ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(dummy.data_ptr()), B, 1, None,
+                               ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(dummy.data_ptr()), 1 << 40, None)
+    assert rc == -1, rc
+    with pytest.raises(_lib.PiccoloHipError):
+        ops.Cloud(torch.zeros(n + 1, 3, device="cuda"), torch.zeros(n + 1, 3, device="cuda"))
