@@ -224,3 +224,27 @@ def test_maximum_cloud_size_vs_oracle(ops, oracle, parity):
     assert rc == -1, rc
     with pytest.raises(_lib.PiccoloHipError):
         ops.Cloud(torch.zeros(n + 1, 3, device="cuda"), torch.zeros(n + 1, 3, device="cuda"))
+
+
+def test_maximum_panorama_size_vs_oracle(ops, oracle, parity):
+    """A 16384 x 8192 panorama: 134M fp16-level texels = 1.07 GB, just under the 2 GiB the texture's 32-bit buffer descriptor
+    addresses (the same image as float4 texels, 2.1 GB, is refused).  Random 8-bit levels, no black pixel: nothing masked,
+    every texel boundary a gradient jump; 200k points, 4 poses vs the fp64 oracle."""
+    from piccolo_amd import _lib, synth
+    n, H, W, B = 200_000, 8192, 16384, 4
+    xyz, rgb = synth.box_room(n, 11)
+    rng = np.random.default_rng(11)
+    # smooth-ish random image: 64 x 128 random levels upsampled by 128 with a little per-pixel noise, quantised to k/255
+    coarse = rng.integers(40, 216, size=(H // 128, W // 128, 3)).astype(np.float32)
+    img = np.repeat(np.repeat(coarse, 128, 0), 128, 1)
+    img += rng.integers(-20, 21, size=(H, W, 1)).astype(np.float32)
+    img = (np.clip(img, 1, 255) / 255.0).astype(np.float32)
+    t_gt, ypr_gt = synth.gt_pose(11)
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=11)
+    pano = ops.Pano(T(img))
+    assert pano.fmt == _lib.PANO_F16
+    out = ops.sampling_loss(ops.Cloud(T(xyz), T(rgb)), pano, T(trans), T(rot), with_grad=True).cpu().numpy()
+    r64, r32 = _oracle_pair(oracle, xyz, rgb, img, trans, rot)
+    _check_vs_oracle(parity, out, r64, r32, n, "16384x8192: ")
+    with pytest.raises(_lib.PiccoloHipError):                        # float4 texels of this size: 2.1 GB > 2 GiB
+        ops.sampling_loss(ops.Cloud(T(xyz), T(rgb)), ops.Pano(T(img), fmt="f32"), T(trans), T(rot), with_grad=True)
