@@ -418,3 +418,31 @@ def test_results_do_not_depend_on_the_block_to_xcd_mapping():
         digests[(runs, flip)] = out.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
     assert len(hashlib.sha256(b"").hexdigest()) == len(next(iter(digests.values())))
+
+
+@pytest.mark.gpu
+def test_cached_engines_survive_alternating_clouds_sizes_and_eviction(oracle):
+    """The cached GradientDescent engines (one per cloud and launch shape, graph replay for small problems) hold device
+    addresses inside captured graphs.  Alternate between two clouds, two image sizes and two candidate counts for long
+    enough that engines are evicted and rebuilt (8 combinations cycle through a cache of 6), and check every result against an eager, uncached refinement of the same inputs, bit for bit."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    base = dict(lr=0.1, num_iter=12, patience=3, factor=0.8, out_of_room_quantile=0.05)
+    clouds = []
+    for seed, n in ((101, 15_000), (102, 22_001)):
+        xyz, rgb = synth.box_room(n, seed)
+        clouds.append((xyz, rgb, torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()))
+    po._cache.clear()
+    combos = [(c, hw, B) for c in (0, 1) for hw in ((48, 96), (64, 128)) for B in (2, 4)]
+    assert len(combos) > po._CAPACITY["gd"]
+    for rep in range(3):
+        for k, (c, (H, W), B) in enumerate(combos):
+            xyz, rgb, X, C = clouds[c]
+            t_gt, ypr_gt = synth.gt_pose(200 + 7 * rep + k)
+            img = torch.from_numpy(oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255).cuda()
+            tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=300 + 7 * rep + k)
+            tr, ro = torch.from_numpy(tr).cuda(), torch.from_numpy(ro).cuda()
+            want = po.omniloc_batch(img, X, C, tr.clone(), ro.clone(), Cfg(gd_graph=False, num_input=B, **base), {})
+            got = po.omniloc_batch(img, X, C, tr.clone(), ro.clone(), Cfg(num_input=B, **base), {})
+            assert all(torch.equal(a, b) for a, b in zip(want, got)), (rep, k)
+    assert len(po._cache.kinds["gd"]) <= po._CAPACITY["gd"]
