@@ -304,23 +304,30 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     for (int i = threadIdx.x; i < TW * TW; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
     for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
     __syncthreads();
-    // four entries in flight per lane (the lists of the heavy tiles — up to 68k entries at 1M points, 30x the mean — are
-    // walked by one workgroup)
-    constexpr int UNR = 4;
-    for (int e = e0 + threadIdx.x; e < e1; e += UNR * PCL_RESOLVE_THREADS) {
-        uint32_t pixv[UNR], depv[UNR], idv[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const int eu = e + u * PCL_RESOLVE_THREADS;
-            const bool ok = eu < e1;
-            pixv[u] = ok ? list[eu] : 0xffffffffu;
-            depv[u] = ok ? list[a.cap + eu] : 0u;
-            idv[u] = ok ? list[2 * a.cap + eu] : 0u;
+    // The list is walked in slabs of PCL_RESOLVE_THREADS entries staged through LDS: the loads are coalesced (lane = entry),
+    // but the entries of a list are Morton neighbours — 64 consecutive ones land on a handful of pixels, and LDS atomics of
+    // one wave on one address serialise.  Each lane therefore takes entry (17 tid) mod 1024 of the slab: a wave's lanes hold
+    // entries from all over the slab (stride 17: no bank conflicts on the way out either).  The next slab's loads are in flight
+    // while the current one is resolved.  Per-workgroup timeline (tools/hist_trace.py) of a 4000-16000-entry list: walk 21.4 ->
+    // 17.6 us; with the atomics compiled out 13.7, with the tile reads out as well 9.9 — over half of the walk is the list
+    // itself arriving from memory (12 B per entry, 2.5 TB/s over the whole launch).
+    __shared__ uint32_t slab[3][PCL_RESOLVE_THREADS];
+    uint32_t npix = 0xffffffffu, ndep = 0u, nid = 0u;
+    {
+        const int e = e0 + (int)threadIdx.x;
+        if (e < e1) { npix = list[e]; ndep = list[a.cap + e]; nid = list[2 * a.cap + e]; }
+    }
+    const int j = ((int)threadIdx.x * 17) & (PCL_RESOLVE_THREADS - 1);
+    for (int base = e0; base < e1; base += PCL_RESOLVE_THREADS) {
+        slab[0][threadIdx.x] = npix; slab[1][threadIdx.x] = ndep; slab[2][threadIdx.x] = nid;
+        __syncthreads();
+        {
+            const int e = base + PCL_RESOLVE_THREADS + (int)threadIdx.x;
+            npix = 0xffffffffu;
+            if (e < e1) { npix = list[e]; ndep = list[a.cap + e]; nid = list[2 * a.cap + e]; }
         }
-#pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            if (pixv[u] == 0xffffffffu) continue;
-            const uint32_t pix = pixv[u], dbits = depv[u], i = idv[u];
+        const uint32_t pix = slab[0][j], dbits = slab[1][j], i = slab[2][j];
+        if (pix != 0xffffffffu) {
             const int row = (int)(pix >> 16), col = (int)(pix & 0xffffu);
             const unsigned long long bk = ((unsigned long long)dbits << 29) | (unsigned long long)(0x1fffffffu - i);
             // clamped at the image border as the reference's index arithmetic is (utils.py:173-198), then tile-local
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
             unsigned long long cur[9];
 #pragma unroll
             // (relaxed atomic loads, not volatile ones: a volatile read of LDS compiles to a system-coherent FLAT load with a
-            // full wait behind it — nine serial round trips through the memory pipeline per entry, which was 80 % of this kernel)
+            // full wait behind it — nine serial round trips through the memory pipeline per entry)
             for (int p = 0; p < 9; p++)
                 cur[p] = __hip_atomic_load(&tile[r3[drow[p] + 1] + c3[dcol[p] + 1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
@@ -342,6 +349,7 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
                 if (key < cur[p]) atomicMin(&tile[r3[drow[p] + 1] + c3[dcol[p] + 1]], key);
             }
         }
+        __syncthreads();                               // the slab is overwritten at the top of the next trip
     }
     __syncthreads();
 #ifdef PCL_BLOCK_TRACE
