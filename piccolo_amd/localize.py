@@ -141,6 +141,24 @@ def _save_result_image(path, gt_img8, xyz, rgb, t, R, resolution):
     Image.fromarray(np.concatenate([gt, np.asarray(render, np.uint8)], axis=0)).save(path)
 
 
+def _save_starting_points(dirname, stem, gt_img8, xyz, rgb, input_trans, input_rot):
+    """cfg.save_starting_point (localize.py:457-471): for every starting pose of the refinement, the query panorama stacked over
+    the cloud rendered from that pose at half the panorama's resolution, as <dirname>/<stem>_<idx>.png."""
+    from .utils import rot_from_ypr
+    for idx in range(int(input_trans.shape[0])):
+        R = rot_from_ypr(input_rot[idx].detach().cpu()).float()
+        _save_result_image(os.path.join(dirname, "{}_{}.png".format(stem, idx)), gt_img8, xyz, rgb,
+                           input_trans[idx].detach().cpu().float(), R, (gt_img8.shape[0] // 2, gt_img8.shape[1] // 2))
+
+
+def _require_gravity_aligned(cfg):
+    """localize.py:141,155-157 / :355,370-372: with gravity_aligned = False the reference calls data_utils.obtain_align_matrix,
+    which its data_utils.py does not define (AttributeError on the first room); refused here before anything is loaded."""
+    if not getattr(cfg, "gravity_aligned", True):
+        raise NotImplementedError("gravity_aligned = False: the reference's own path stops at the undefined "
+                                  "data_utils.obtain_align_matrix (localize.py:155); align the cloud beforehand")
+
+
 def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, row_prefix):
     """Shared loop of the two dataset harnesses: shard the query images over the ranks, run `per_image(k)` ->
     (RESULT_WIDTH row, gt_trans, gt_rot, skipped), gather, and let rank 0 write the reference's CSV and accuracy."""
@@ -222,7 +240,7 @@ def _nan_row():
     return torch.full((pdist.RESULT_WIDTH,), float("nan"))
 
 
-def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries, batcher=None, finish=None):
+def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries, batcher=None, finish=None, on_start=None):
     """localize.py:199-247: make_input on the initialisation image, refinement on the main image, errors.  With a
     `batcher` the refinement is deferred: images of one cloud are refined together, `finish(t, R, row)` is called then."""
     init_dict = get_init_dict(cfg)
@@ -230,6 +248,8 @@ def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summa
     t0 = time.time()
     input_trans, input_rot = make_input(img_init, xyz, rgb, getattr(cfg, "num_input", 6), init_dict,
                                         getattr(cfg, "criterion", "histogram"), getattr(cfg, "num_intermediate", 20))
+    if on_start is not None:
+        on_start(input_trans, input_rot)
     if batcher is not None:
         torch.cuda.synchronize()
         batcher.submit(dict(img=img_main, xyz=xyz, rgb=rgb, trans=input_trans, rot=input_rot, gt=(gt_trans, gt_rot),
@@ -282,6 +302,7 @@ class _Batcher:
 def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford"):
     """Stanford2D-3D-S loop (localize.py:76-297) over `root`/pano/area_*/ *.png, pcd_not_aligned/area_*/<room>.txt and
     pose/area_*/ *.json; writes `stanford_results.csv` with the reference's columns and result images under results/."""
+    _require_gravity_aligned(cfg)
     _seed_all()
     dev = ops.device()
     area_num = getattr(cfg, "area", None)
@@ -354,6 +375,7 @@ def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscen
     """OmniScenes loop (localize.py:300-530) over `root`/<split>_pano/<video>/<frame>, pcd/<room>.txt and <split>_pose;
     writes `omniscenes_results.csv`.  Includes the synthetic illumination changes (synth_const / synth_gamma / synth_wb)
     and the colour preprocessing of the whole image (match_color / sharpen_color)."""
+    _require_gravity_aligned(cfg)
     _seed_all()
     dev = ops.device()
     split = getattr(cfg, "split_name", "extreme")
@@ -410,10 +432,16 @@ def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscen
             if done is not None:
                 done(row)
 
+        on_start = None
+        if getattr(cfg, "save_starting_point", False) and log_dir is not None:
+            def on_start(input_trans, input_rot):
+                _save_starting_points(os.path.join(log_dir, "starting_points", video), os.path.splitext(filename.split("/")[-1])[0],
+                                      orig, xyz, rgb_k, input_trans, input_rot)
         if batcher is not None:
-            _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries, batcher=batcher, finish=report)
+            _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries, batcher=batcher, finish=report,
+                              on_start=on_start)
             return None, gt_trans, gt_rot, False
-        t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries)
+        t, R, row = _refine_and_score(img, img_main, xyz, rgb_k, cfg, gt_trans, gt_rot, summaries, on_start=on_start)
         report(t, R, row)
         return row, gt_trans, gt_rot, False
 

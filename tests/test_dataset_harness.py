@@ -139,11 +139,22 @@ def test_localize_omniscenes_layout(tmp_path):
         assert len(list(csv.reader(f))) == 3
     # images_per_launch: both frames of the room refined in one launch chain (same cloud tensors, same image size); every
     # frame still gets its own row; frame 1 again localised
-    both = localize.localize_omniscenes(Cfg(images_per_launch=4, **base), None, str(tmp_path / "log3"), root=str(root)).cpu().numpy()
+    both = localize.localize_omniscenes(Cfg(images_per_launch=4, save_starting_point=True, **base), None, str(tmp_path / "log3"),
+                                        root=str(root)).cpu().numpy()
     assert both.shape == (2, 16) and np.isfinite(both).all() and both[1, 13] < 0.08 and both[1, 14] < 1.5
     with open(tmp_path / "log3" / "omniscenes_results.csv") as f:
         assert len(list(csv.reader(f))) == 3
     assert (tmp_path / "log3" / "results" / video / "000001.png").exists()
+    # cfg.save_starting_point (localize.py:457-471): one stacked query / render image per starting pose and frame, at half the
+    # 2048 x 1024 frame's resolution
+    for frame in ("000000", "000001"):
+        for idx in range(COMMON["num_input"]):
+            pth = tmp_path / "log3" / "starting_points" / video / ("%s_%d.png" % (frame, idx))
+            assert pth.exists(), pth
+    assert Image.open(tmp_path / "log3" / "starting_points" / video / "000001_0.png").size == (1024, 1024)
+    # gravity_aligned = False: the reference's own path stops at an undefined helper; refused up front here
+    with pytest.raises(NotImplementedError):
+        localize.localize_omniscenes(Cfg(gravity_aligned=False, **base), None, str(tmp_path / "log4"), root=str(root))
     # filters of the loop
     none = localize.localize_omniscenes(Cfg(**{**base, "scene_number": 7}), None, None, root=str(root))
     assert tuple(none.shape) == (0, 16)
