@@ -97,7 +97,8 @@ def resize_image(img8, width, height):
     """uint8 (H,W,3) -> (height,width,3), bilinear with OpenCV's INTER_LINEAR geometry (pixel centres at k + 0.5, edge
     clamp, no antialiasing; cv2.resize at localize.py:168,211,372).  Identity when the size is unchanged, which is the
     case for all shipped configs on 2048 x 1024 panoramas.  cv2 interpolates in 11-bit fixed point: results may differ
-    from it by one level — parity unpinned (OpenCV is absent from the build image)."""
+    from it by one level — parity unpinned against OpenCV (absent from the build image); torch's F.interpolate(bilinear,
+    align_corners=False, antialias=False), the same geometry, agrees within half a level (tests/test_dataset_harness.py)."""
     H, W = img8.shape[:2]
     if (W, H) == (width, height):
         return img8

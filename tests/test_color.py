@@ -244,3 +244,21 @@ def test_histogram_reference_golden(cu, tag, channels):
     assert abs(float(cu.histogram_intersection(h_unit, h_255)) - float(g[tag + "_inter"])) <= 1e-6
     ib = cu.histogram_intersection(hb, hb.flip(0)).cpu().numpy()
     assert np.abs(ib - g[tag + "_inter_batched"]).max() <= 1e-6
+
+
+def test_ycrcb_pair_agrees_with_pillow_within_one_level_over_the_whole_cube():
+    """OpenCV is absent, so cv2.cvtColor itself cannot be the pin — but Pillow's RGB <-> YCbCr (the JPEG / BT.601 full-range
+    transform) is the same map up to OpenCV's rounded constants (.713 ~ .5 / (1 - .299), .564 ~ .5 / (1 - .114)) and its
+    fixed-point rounding: the restatement must stay within ONE 8-bit level of that independent implementation on every one of
+    the 2^24 colours, in both directions.  (A wrong coefficient, a swapped Cr / Cb or a missing +128 is tens of levels.)"""
+    from PIL import Image
+    v = np.arange(256, dtype=np.uint8)
+    for c0 in range(0, 256, 32):                                    # 8 slabs of 32 x 256 x 256 colours
+        cube = np.stack(np.meshgrid(v[c0:c0 + 32], v, v, indexing="ij"), -1).reshape(-1, 256, 3)
+        mine = ocolor.rgb2ycrcb_u8(cube).astype(np.int16)           # Y, Cr, Cb
+        pil = np.asarray(Image.fromarray(cube, "RGB").convert("YCbCr")).astype(np.int16)      # Y, Cb, Cr
+        assert np.abs(mine[..., 0] - pil[..., 0]).max() <= 1
+        assert np.abs(mine[..., 1] - pil[..., 2]).max() <= 1 and np.abs(mine[..., 2] - pil[..., 1]).max() <= 1
+        back = ocolor.ycrcb2rgb_u8(cube).astype(np.int16)           # the same triples read as (Y, Cr, Cb)
+        pil_back = np.asarray(Image.fromarray(np.ascontiguousarray(cube[..., [0, 2, 1]]), "YCbCr").convert("RGB")).astype(np.int16)
+        assert np.abs(back - pil_back).max() <= 1

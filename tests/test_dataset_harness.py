@@ -170,3 +170,22 @@ def test_resize_image_geometry():
     assert np.abs(half.astype(np.float64) - box).max() <= 0.5 + 1e-9
     up = resize_image(img, 32, 16)
     assert up.shape == (16, 32, 3) and up.min() >= img.min() and up.max() <= img.max()
+
+
+def test_resize_image_agrees_with_torch_bilinear_within_one_level():
+    """cv2.resize (INTER_LINEAR: pixel centres at k + 0.5, edge clamp, no antialiasing) is absent; torch's
+    F.interpolate(mode="bilinear", align_corners=False, antialias=False) is an independent implementation of the same
+    geometry.  The restatement must agree with it to one 8-bit level (rounding of .5 ties) for down- and up-scaling by integer
+    and non-integer factors — the factors the configs use (init / main_downsample_h, _w) and the 2048 x 1024 normalisation
+    of the OmniScenes loop."""
+    import torch.nn.functional as Fn
+    from piccolo_amd.utils import resize_image
+    rng = np.random.default_rng(5)
+    for (H, W), (h, w) in (((64, 128), (32, 64)), ((64, 128), (16, 32)), ((60, 100), (45, 80)), ((48, 96), (96, 192)),
+                           ((50, 70), (128, 256)), ((96, 200), (32, 50))):
+        img = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        mine = resize_image(img, w, h).astype(np.int16)
+        ref = Fn.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(h, w), mode="bilinear", align_corners=False,
+                             antialias=False)[0].permute(1, 2, 0).numpy()
+        assert mine.shape == (h, w, 3)
+        assert np.abs(mine - ref).max() <= 0.5 + 1e-6, ((H, W), (h, w), np.abs(mine - ref).max())
