@@ -2,6 +2,7 @@
 // Wavefront = 64 lanes everywhere; no other target is supported.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/piccolo_hip.h"
@@ -23,6 +24,8 @@ struct PclPoseRec {
     float pad[2];
 };
 static_assert(sizeof(PclPoseRec) == 64, "pose record is one 64-byte scalar-load line");
+// pcl_project2 (pcl_loss.hip) reads R and t as six consecutive 64-bit SGPR pairs (R0,R1) ... (R8,t0) (t1,t2)
+static_assert(offsetof(PclPoseRec, R) == 0 && offsetof(PclPoseRec, t) == 36, "pose record: t directly after R[9]");
 
 // Per-candidate optimiser state of the on-device GD loop (pcl_gd.hip).
 struct PclGdPose {

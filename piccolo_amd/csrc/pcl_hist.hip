@@ -498,6 +498,13 @@ static int pcl_hist_env_int(const char* name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
+// can the tile-binned render be used at all for this cloud / panorama (16-bit pixel fields, 28-bit slots, <= 4096 tiles)?
+static bool hist_binned_ok(int64_t n, int H, int W)
+{
+    const int64_t nt = (int64_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
+    return nt <= 4096 && H < 65536 && W < 65536 && n < ((int64_t)1 << 28);
+}
+
 // bytes of the render area per candidate: the z-buffer of the splat path, or — when n is given — the larger of that and the
 // tile-binned path's bookkeeping + point lists (4 n entries of 12 bytes: the exact worst case, nothing can overflow)
 static size_t hist_render_bytes(int64_t n, int H, int W)
@@ -505,6 +512,7 @@ static size_t hist_render_bytes(int64_t n, int H, int W)
     size_t zb = (size_t)H * W * 8;
     if (n <= 0) return zb;
     const size_t nt = (size_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
+    if (!hist_binned_ok(n, H, W)) return zb;       // the launch would take the splat path anyway: no lists to hold
     size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12;
     return binned > zb ? binned : zb;
 }
@@ -549,7 +557,8 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     ws += hist_align((size_t)nblk * PCL_HBINS * sizeof(float));
     unsigned int* ghist_q = (unsigned int*)ws;                       // [nblk][512], then [ncand][nblk][512]
     unsigned int* ghist_c = ghist_q + (size_t)nblk * PCL_HBINS;
-    (void)hipMemsetAsync(ghist_q, 0, (size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int), s);
+    hipError_t me = hipMemsetAsync(ghist_q, 0, (size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int), s);
+    if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     const int64_t stride = pcl_cloud_stride(n);
     hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
@@ -560,7 +569,7 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     const int force_splat = pcl_hist_env_int("PCL_HIST_SPLAT", 0);      // (read per call: a handful of calls per image)
     const int ntx = (W + PCL_TS - 1) / PCL_TS, nty = (H + PCL_TS - 1) / PCL_TS, nt = ntx * nty;
     const int64_t cap = 4 * n;
-    if (!force_splat && roomy && nt <= 4096 && H < 65536 && W < 65536 && n < ((int64_t)1 << 28)) {
+    if (!force_splat && roomy && hist_binned_ok(n, H, W)) {
         PclBinArgs b;
         b.cloud = cloud; b.n = n; b.stride = stride; b.poses = recs; b.H = H; b.W = W; b.ntx = ntx; b.nt = nt;
         // layout of the render area: [ncand] x { counts[nt], offsets[nt + 1], cursors[nt], order[nt] }, [ncand] x lists[3][cap]
@@ -571,7 +580,9 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
         b.cap = cap;
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
-        (void)hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
+        // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)
+        me = hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
+        if (me != hipSuccess) return (int)me;
         dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
         hipLaunchKernelGGL(pcl_bin_kernel<false>, pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
         hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);

@@ -223,7 +223,7 @@ struct PclProj {
 
 // Phase A: q = x - t, p = R q, cloud2idx, clip, pixel + fractions, issue the gathers.
 template <int FMT>
-__device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __restrict__ R, const float* __restrict__ t,
+__device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPoseRec* __restrict__ pose,
                                              __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
 {
     // q = x - t ; p = R q                                                   (omniloc.py:190-191, :332-338)
@@ -232,8 +232,10 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const float* __re
     // pair of its own (s_mov x2), 24 SGPRs per pose that it then spills to VGPR lanes and reads back with v_readlane
     // inside the loop.  Dependent packed-fp32 ops need one instruction between them (the compiler puts s_nop there):
     // the three rows are interleaved, so every result is used three slots later; same operations in the same order.
+    // (The pairs rely on PclPoseRec's layout — t directly behind R[9], static_assert in pcl_device.h — and on the pose
+    // pointer being wave-uniform: the "s" constraints below.)
     {
-        const f2* __restrict__ P = reinterpret_cast<const f2*>(R);
+        const f2* __restrict__ P = reinterpret_cast<const f2*>(pose->R);
         const f2 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5];
         f2 qx, qy, qz, px, py, pz;
         asm("v_pk_add_f32 %3, %6, %13 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // qx = x - t0   (hi of p4)
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
-            pcl_project2<FMT>(x, y, z, pr->R, pr->t, tg, a.dims, pj);
+            pcl_project2<FMT>(x, y, z, pr, tg, a.dims, pj);
             pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tg, a.dims, acc[g], count[g]);
         }
     };

@@ -741,12 +741,50 @@ def g20_standalone_backward():
     save("g20_standalone_backward.npz", **out)
 
 
+# ----------------------------------------------------------------------------- G21
+def g21_full_size_batch_loss():
+    """The reference's own BatchSamplingLoss (omniloc.py:299-356) + autograd at BASELINE config 2's FULL size: 1M points,
+    2048x1024 panorama, 32 candidate poses — in fp32 (what the reference computes) and in fp64.  The scene is the bench's
+    (synth.box_room(1M, seed 0), image 0's ground truth and starting poses) with the panorama rendered by the deterministic
+    C oracle renderer, so the GPU test regenerates the inputs from the seeds; only outputs and input checksums are stored.
+    ~1 min in fp32 and ~2 min in fp64 on 8 cores, peak RSS ~8 GB."""
+    from oracle import oracle as orc
+    N, H, W, B = 1_000_000, 1024, 2048, 32
+    xyz, rgb = synth.box_room(N, seed=0)
+    t_gt, ypr_gt = synth.gt_pose(0)
+    img_u8 = orc.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W))
+    img = img_u8.astype(np.float32) / 255.0
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=0)
+    res = {}
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            mod = ref_omniloc.BatchSamplingLoss(torch.from_numpy(xyz).to(dtype), torch.from_numpy(rgb).to(dtype),
+                                                torch.from_numpy(img).to(dtype), torch.device("cpu"), Cfg(num_input=B))
+            t = torch.tensor(trans, dtype=dtype).unsqueeze(-1).requires_grad_()
+            yaw = torch.tensor(rot[:, 0:1], dtype=dtype).requires_grad_()
+            pitch = torch.tensor(rot[:, 1:2], dtype=dtype).requires_grad_()
+            roll = torch.tensor(rot[:, 2:3], dtype=dtype).requires_grad_()
+            loss, loss_list = mod(t, yaw, pitch, roll)
+            loss.backward()
+            res["loss_list_" + tag] = loss_list.detach().numpy()
+            res["grad_t_" + tag] = t.grad.squeeze(-1).numpy()
+            res["grad_ypr_" + tag] = torch.cat([yaw.grad, pitch.grad, roll.grad], 1).numpy()
+            print("G21", tag, "done", flush=True)
+            del mod, loss, loss_list, t, yaw, pitch, roll
+        finally:
+            torch.set_default_dtype(old)
+    save("g21_full_size_batch_loss.npz", N=N, H=H, W=W, B=B, trans=trans, rot=rot, img_sum=int(img_u8.astype(np.int64).sum()),
+         xyz_sum=float(xyz.astype(np.float64).sum()), rgb_sum=float(rgb.astype(np.float64).sum()), **res)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
             g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils,
             g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks,
-            g20_standalone_backward]
+            g20_standalone_backward, g21_full_size_batch_loss]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

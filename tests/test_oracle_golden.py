@@ -314,10 +314,17 @@ def g18_compare(rows, ref, record):
     record("recovered translation vs the reference's, median over seeds (m)", np.median(d_p), 2.5 * np.median(self_p) + 2e-4, np.median(self_p))
     record("t-err distance to the reference, worst seed (m)", d_t.max(), 2.5 * self_t.max(), self_t.max())
     record("R-err distance to the reference, worst seed (deg)", d_r.max(), 2.5 * self_r.max(), self_r.max())
-    record("median t-err over seeds vs the reference's median (m)", abs(np.median(rows[:, 13]) - np.median(ref[:, 0, 13])),
-           2.5 * abs(np.median(ref[:, 0, 13]) - np.median(ref[:, 1, 13])) + 5e-4)
-    record("median R-err over seeds vs the reference's median (deg)", abs(np.median(rows[:, 14]) - np.median(ref[:, 0, 14])),
-           2.5 * abs(np.median(ref[:, 0, 14]) - np.median(ref[:, 1, 14])) + 1e-2)
+    # Medians over the scenes: the reference's two runs differ in their medians by an amount that is itself one draw of a
+    # noisy statistic (seq: 1.2e-4 m observed, while a paired bootstrap over the 32 scenes gives that difference a standard
+    # deviation of 5.8e-4 m).  Bound = the observed difference + 3 bootstrap standard deviations of it (seeded resampling of the
+    # scenes, both runs resampled together) — round 2's 2.5 x observed + 5e-4 passed at 76-86 % on one box by luck of the draw.
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, len(ref), size=(4000, len(ref)))
+    for col, what, unit in ((13, "t-err", "m"), (14, "R-err", "deg")):
+        a, b = ref[:, 0, col], ref[:, 1, col]
+        spread = (np.median(a[idx], 1) - np.median(b[idx], 1)).std()
+        record("median %s over seeds vs the reference's median (%s)" % (what, unit), abs(np.median(rows[:, col]) - np.median(a)),
+               abs(np.median(a) - np.median(b)) + 3.0 * spread, spread)
 
 
 def test_oracle_end_to_end_32_seeds_within_reference_self_noise(oracle, parity):
@@ -334,6 +341,39 @@ def test_oracle_end_to_end_32_seeds_within_reference_self_noise(oracle, parity):
         t, R = r[0].reshape(3), r[1]
         rows.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
     g18_compare(np.array(rows), g["seq"], parity)
+
+
+# G21 -----------------------------------------------------------------------------------------
+def g21_scene(oracle, g):
+    """The scene of G21 = the bench's cfg-2 scene (box_room(1M, seed 0), ground truth and 32 starting poses of image 0), the
+    panorama from the deterministic oracle renderer; checked against the fixture's checksums."""
+    from piccolo_amd import synth
+    N, H, W, B = int(g["N"]), int(g["H"]), int(g["W"]), int(g["B"])
+    xyz, rgb = synth.box_room(N, seed=0)
+    t_gt, ypr_gt = synth.gt_pose(0)
+    img_u8 = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W))
+    assert int(img_u8.astype(np.int64).sum()) == int(g["img_sum"]), "G21 panorama differs from the generator's"
+    assert float(xyz.astype(np.float64).sum()) == float(g["xyz_sum"]) and float(rgb.astype(np.float64).sum()) == float(g["rgb_sum"])
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=0)
+    assert np.array_equal(trans, g["trans"]) and np.array_equal(rot, g["rot"])
+    return xyz, rgb, img_u8.astype(np.float32) / 255.0, trans, rot
+
+
+def test_oracle_at_full_cfg2_size_equals_the_reference(oracle, parity):
+    """G21: the reference's own BatchSamplingLoss + autograd at BASELINE config 2's full size (1M points, 2048x1024, 32 poses),
+    fp32 and fp64.  The fp64 oracle must reproduce the reference's fp64 numbers to rounding; the fp32 oracle's distance from
+    fp64 is the reference's own fp32 distance (both ~1.2e-3 on the gradient: texel-cell flips of ~100 of the 1M points)."""
+    g = load_golden("g21_full_size_batch_loss.npz")
+    xyz, rgb, img, trans, rot = g21_scene(oracle, g)
+    r64 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64)
+    parity("G21 oracle fp64 vs reference fp64: loss_list", rel(r64["loss"], g["loss_list_f64"]), 1e-12)
+    parity("G21 oracle fp64 vs reference fp64: grad_t", rel(r64["grad_t"], g["grad_t_f64"]), 1e-11)
+    parity("G21 oracle fp64 vs reference fp64: grad_ypr", rel(r64["grad_ypr"], g["grad_ypr_f64"]), 1e-11)
+    r32 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float32)
+    for key, gk in (("loss", "loss_list"), ("grad_t", "grad_t"), ("grad_ypr", "grad_ypr")):
+        gap_ref = rel(g[gk + "_f32"], g[gk + "_f64"])
+        parity("G21 fp32 oracle vs reference fp64: %s (yardstick: the reference's fp32)" % key, rel(r32[key], g[gk + "_f64"]),
+               2 * gap_ref, gap_ref)
 
 
 # G12 -----------------------------------------------------------------------------------------
