@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 4 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n */
+#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -38,6 +38,11 @@ extern "C" {
 
 int pcl_abi_version(void);
 const char *pcl_error_string(int code);
+/* Which sources the loss kernel of THIS binary was compiled from: the first 16 hex digits of sha256(csrc/pcl_loss.hip +
+ * csrc/pcl_device.h), stamped in by piccolo_amd/build.py ("unstamped" for a build that did not pass -DPCL_SOURCE_HASH).
+ * Measurement aid: counter-derived figures (VALU instructions per point-pose, profiles/roofs.json) carry the hash of the
+ * library they were collected from, and bench.py reports them only for a library with the same hash. */
+const char *pcl_source_hash(void);
 
 /* ---- data layout in HBM ------------------------------------------------------------------------------------
  * cloud : 6 planes (x, y, z, -r, -g, -b) of pcl_cloud_stride(n) floats each (colours negated: the loss needs c - rgb) — SoA so that a wavefront's 64 lanes
@@ -154,6 +159,11 @@ void pcl_timer_destroy(void *timer);
 void pcl_timer_reset(void *timer);
 void pcl_timer_set_stride(void *timer, int stride); /* time only every stride-th launch of a run (default 1) */
 int pcl_timer_read(void *timer, double *total_ms_host, int *launches_host);
+/* What an event pair reads with NOTHING between its two records: `reps` empty pairs are recorded on `stream`, the call
+ * synchronises on them and returns their median elapsed time (ms).  A pair around a kernel over-reads the kernel's duration
+ * by about this much (the two event packets' own processing); bench.py subtracts it per timed launch.  Uses its own events,
+ * leaves the timer's recorded pairs untouched. */
+int pcl_timer_calibrate(void *timer, int reps, double *pair_ms_host, void *stream);
 
 /* ---- stand-alone ops of the path ---------------------------------------------------------------------------- */
 /* utils.py:16-61 cloud2idx: xyz [n][3] -> coord [n][2] in [-1,1]^2 (batched form = same call on B*n points). */

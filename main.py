@@ -5,7 +5,10 @@ dataset = Synthetic runs piccolo_amd.localize.localize_synthetic (no dataset fil
 run piccolo_amd.localize.localize_stanford / localize_omniscenes over ./data/... in the reference's directory layout
 (README.md:40-75 of the reference) and write the reference's CSV.  The reference's own main.py can also be run on top of
 this package — dropin/run_reference.py, see INTEGRATION.md.  With torch.distributed.run the query images are sharded
-over the GPUs.
+over the GPUs:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -- main.py --config ... --log ...
+(the `--` matters: torchrun's argument parser otherwise rejects the reference CLI's `--log` as an ambiguous abbreviation of
+its own --log-dir / --logs-specs).
 """
 import argparse
 import os
@@ -41,8 +44,21 @@ def main():
     import torch.distributed as dist
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # One process per GPU over RCCL.  PCL_DIST_BACKEND=gloo (the knob bench.py has) lets several ranks share the GPUs that
+        # are there — how the test-suite runs this very loop with two ranks on a one-GPU box.
+        backend = os.environ.get("PCL_DIST_BACKEND", "nccl")
+        local_rank, n_dev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+        if n_dev < 1:
+            raise SystemExit("main.py needs an MI355X: torch.cuda.device_count() == 0")
+        if backend == "nccl" and n_dev <= local_rank:
+            raise SystemExit("local rank %d but only %d GPU(s) visible: one rank per GPU is required for the RCCL run" % (local_rank, n_dev))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev_index = local_rank if backend == "nccl" else local_rank % n_dev
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     from piccolo_amd import localize
     run = {"Synthetic": localize.localize_synthetic, "Stanford2D-3D-S": localize.localize_stanford,
            "OmniScenes": localize.localize_omniscenes}[cfg.dataset]

@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
@@ -27,6 +27,7 @@ class GdHyper(_c.Structure):
 SIGNATURES = {
     "pcl_abi_version": (_int, []),
     "pcl_error_string": (_c.c_char_p, [_int]),
+    "pcl_source_hash": (_c.c_char_p, []),
     "pcl_cloud_stride": (_i64, [_i64]),
     "pcl_cloud_bytes": (_sz, [_i64]),
     "pcl_cloud_pack": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "pcl_timer_reset": (None, [_vp]),
     "pcl_timer_set_stride": (None, [_vp, _int]),
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
+    "pcl_timer_calibrate": (_int, [_vp, _int, _c.POINTER(_dbl), _vp]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),

@@ -26,6 +26,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def loss_kernel_source_hash():
+    """First 16 hex digits of sha256(csrc/pcl_loss.hip + csrc/pcl_device.h): what pcl_source_hash() of a library built from this
+    tree returns.  Counter-derived figures in profiles/roofs.json carry it; bench.py reports them only when it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("pcl_loss.hip", "pcl_device.h"):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(SO):
         return True
@@ -40,7 +51,7 @@ def build(force=False, verbose=False, extra_flags=()):
         return SO
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread",
-           "-Wall", "-Wno-unused-function", "-o", SO] + list(extra_flags) + sources()
+           "-Wall", "-Wno-unused-function", '-DPCL_SOURCE_HASH="%s"' % loss_kernel_source_hash(), "-o", SO] + list(extra_flags) + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -195,6 +195,37 @@ extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_
     return 0;
 }
 
+extern "C" int pcl_timer_calibrate(void* timer, int reps, double* pair_ms_host, void* stream)
+{
+    if (!timer || !pair_ms_host || reps <= 0 || reps > 4096) return PCL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a);
+    if (e != hipSuccess) return (int)e;
+    e = hipEventCreate(&b);
+    if (e != hipSuccess) { (void)hipEventDestroy(a); return (int)e; }
+    float* ms = new float[reps];
+    int got = 0;
+    for (int i = 0; i < reps && e == hipSuccess; i++) {
+        e = hipEventRecord(a, s);
+        if (e == hipSuccess) e = hipEventRecord(b, s);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[got], a, b);
+        if (e == hipSuccess) got++;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (e == hipSuccess) {
+        for (int i = 1; i < got; i++) {                      // insertion sort: a few dozen values
+            float v = ms[i]; int j = i - 1;
+            while (j >= 0 && ms[j] > v) { ms[j + 1] = ms[j]; j--; }
+            ms[j + 1] = v;
+        }
+        *pair_ms_host = (double)ms[got / 2];
+    }
+    delete[] ms;
+    return (int)e;
+}
+
 extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, void* state, int B,
                           const float* box, const pcl_gd_hyper* hyper_host, int num_iter, float* loss_history,
                           void* workspace, size_t workspace_bytes, void* timer, void* stream)

@@ -7,6 +7,11 @@
 
 extern "C" int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 
+#ifndef PCL_SOURCE_HASH
+#define PCL_SOURCE_HASH "unstamped"
+#endif
+extern "C" const char* pcl_source_hash(void) { return PCL_SOURCE_HASH; }
+
 extern "C" const char* pcl_error_string(int code)
 {
     if (code == 0) return "success";

@@ -39,13 +39,18 @@ def gather_rows(local_rows, n_items, rank=None, world_size=None, group=None):
         return local_rows
     import torch.distributed as dist
     per_rank = (n_items + world_size - 1) // world_size
-    block = torch.full((per_rank, width), float("nan"), dtype=local_rows.dtype, device=local_rows.device)
-    block[: local_rows.shape[0]] = local_rows
-    out = torch.empty(world_size * per_rank, width, dtype=local_rows.dtype, device=local_rows.device)
+    # RCCL gathers device tensors in place; gloo (CPU tests, or several ranks sharing one GPU: PCL_DIST_BACKEND=gloo) goes
+    # through host memory
+    home = local_rows.device
+    via_host = dist.get_backend(group) == "gloo" and local_rows.is_cuda
+    dev = torch.device("cpu") if via_host else home
+    block = torch.full((per_rank, width), float("nan"), dtype=local_rows.dtype, device=dev)
+    block[: local_rows.shape[0]] = local_rows.to(dev)
+    out = torch.empty(world_size * per_rank, width, dtype=local_rows.dtype, device=dev)
     dist.all_gather_into_tensor(out, block, group=group)
     # out[r * per_rank + j] is item r + j * world  ->  item-major order
     ordered = out.reshape(world_size, per_rank, width).transpose(0, 1).reshape(per_rank * world_size, width)
-    return ordered[:n_items].contiguous()
+    return ordered[:n_items].contiguous().to(home)
 
 
 def localize_sharded(n_items, refine, device, group=None):

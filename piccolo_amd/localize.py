@@ -159,11 +159,65 @@ def _require_gravity_aligned(cfg):
                                   "data_utils.obtain_align_matrix (localize.py:155); align the cloud beforehand")
 
 
-def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, row_prefix):
-    """Shared loop of the two dataset harnesses: shard the query images over the ranks, run `per_image(k)` ->
-    (RESULT_WIDTH row, gt_trans, gt_rot, skipped), gather, and let rank 0 write the reference's CSV and accuracy."""
-    dev = ops.device()
+def stanford_success(t_err, r_err):
+    """localize.py:250: `(t_error < 0.2) and (r_error < np.rad2deg(0.2))` — 0.2 m and 0.2 rad (11.46 degrees)."""
+    return bool(t_err < 0.2 and r_err < np.rad2deg(0.2))
+
+
+def omniscenes_success(t_err, r_err):
+    """localize.py:513: `(t_error < 0.1) and (r_error < 5)` — 0.1 m and 5 degrees."""
+    return bool(t_err < 0.1 and r_err < 5)
+
+
+LAST_RUN = {}          # rank 0's summary of the latest dataset loop: accuracy, failed / skipped file names (what the reference prints)
+
+
+def write_results(table, gts, filenames, writer, log_dir, csv_name, header, row_prefix, success):
+    """Rank 0's tail of the dataset loops (localize.py:250-297 / :513-530): the CSV in the reference's columns, the running
+    accuracy under the DATASET's own success rule (`success(t_err, r_err)`), failed / skipped rooms.  Pure host code.
+    -> {"accuracy", "well_posed", "total", "failed", "skipped"}."""
+    import contextlib
     writer = writer if writer is not None else _NullWriter()
+    accuracy, well_posed, total = 0.0, 0, 0
+    failed, skipped_list = [], []
+    scalar_summaries = {"current_accuracy": []}
+    if log_dir is not None:
+        os.makedirs(log_dir, exist_ok=True)
+    with (open(os.path.join(log_dir, csv_name), "w", encoding="utf-8", newline="") if log_dir is not None
+          else contextlib.nullcontext(open(os.devnull, "w"))) as f:
+        w = csv.writer(f)
+        w.writerow(header)
+        for k, row in enumerate(np.asarray(table)):
+            gt_t, gt_r, skipped = gts[k]
+            if skipped:
+                skipped_list.append(filenames[k])
+                writer.add_text("skipped rooms", filenames[k])
+                w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 1])
+                continue
+            t_err, r_err = float(row[13]), float(row[14])
+            if success(t_err, r_err):
+                well_posed += 1
+            else:
+                failed.append(filenames[k])
+                writer.add_text("failed rooms", filenames[k])
+            total += 1
+            accuracy = well_posed / total
+            scalar_summaries["current_accuracy"] = [accuracy]
+            write_summaries(writer, scalar_summaries, k)                     # localize.py:295
+            w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 0, _fmt(row[0:3]), _fmt(row[3:12]), t_err, r_err,
+                                                   float(row[15])])
+    writer.add_scalar("final accuracy", accuracy)
+    print("Final Accuracy : {}".format(accuracy))
+    print("failed {} rooms : {}\n".format(len(failed), failed))
+    print("skipped {} rooms : {}".format(len(skipped_list), skipped_list))
+    return {"accuracy": accuracy, "well_posed": well_posed, "total": total, "failed": failed, "skipped": skipped_list}
+
+
+def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, row_prefix, success):
+    """Shared loop of the two dataset harnesses: shard the query images over the ranks, run `per_image(k)` ->
+    (RESULT_WIDTH row, gt_trans, gt_rot, skipped), gather, and let rank 0 write the reference's CSV and the accuracy under
+    the dataset's own success rule (`success`: stanford_success / omniscenes_success)."""
+    dev = ops.device()
     gts = {}
 
     def body(k):
@@ -187,44 +241,13 @@ def _run_dataset(cfg, writer, log_dir, filenames, per_image, csv_name, header, r
     else:
         table = pdist.localize_sharded(len(filenames), body, dev)
     rank, world = pdist.world()
-    if world > 1:                                   # ground truths of the other ranks' images, for the CSV
+    if world > 1 and rank == 0:                     # ground truths of the other ranks' images, for the CSV
         for k in range(len(filenames)):
             if k not in gts:
                 gts[k] = per_image(k, gt_only=True)
-    accuracy, well_posed, total = 0.0, 0, 0
-    failed, skipped_list = [], []
-    scalar_summaries = {"current_accuracy": []}
+    LAST_RUN.clear()
     if rank == 0:
-        import contextlib
-        if log_dir is not None:
-            os.makedirs(log_dir, exist_ok=True)
-        with (open(os.path.join(log_dir, csv_name), "w", encoding="utf-8", newline="") if log_dir is not None
-              else contextlib.nullcontext(open(os.devnull, "w"))) as f:
-            w = csv.writer(f)
-            w.writerow(header)
-            for k, row in enumerate(table.cpu().numpy()):
-                gt_t, gt_r, skipped = gts[k]
-                if skipped:
-                    skipped_list.append(filenames[k])
-                    writer.add_text("skipped rooms", filenames[k])
-                    w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 1])
-                    continue
-                t_err, r_err = float(row[13]), float(row[14])
-                if t_err < 0.2 and r_err < np.rad2deg(0.2):          # localize.py:250
-                    well_posed += 1
-                else:
-                    failed.append(filenames[k])
-                    writer.add_text("failed rooms", filenames[k])
-                total += 1
-                accuracy = well_posed / total
-                scalar_summaries["current_accuracy"] = [accuracy]
-                write_summaries(writer, scalar_summaries, k)                     # localize.py:295
-                w.writerow(row_prefix(filenames[k]) + [_fmt(gt_t), _fmt(gt_r), 0, _fmt(row[0:3]), _fmt(row[3:12]), t_err, r_err,
-                                                       float(row[15])])
-        writer.add_scalar("final accuracy", accuracy)
-        print("Final Accuracy : {}".format(accuracy))
-        print("failed {} rooms : {}\n".format(len(failed), failed))
-        print("skipped {} rooms : {}".format(len(skipped_list), skipped_list))
+        LAST_RUN.update(write_results(table.cpu().numpy(), gts, filenames, writer, log_dir, csv_name, header, row_prefix, success))
     return table
 
 
@@ -368,7 +391,7 @@ def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford")
     return _run_dataset(cfg, writer, log_dir, filenames, per_image, "stanford_results.csv",
                         ["area_num", "pano_name", "gt_trans", "gt_rot", "skipped?", "OmniLoc_trans", "OmniLoc_rot", "t_error (m)",
                          "r_error (degrees)", "time (s)"],
-                        lambda f: [int(f.split("/")[-2].split("_")[-1]), f.split("/")[-1]])
+                        lambda f: [int(f.split("/")[-2].split("_")[-1]), f.split("/")[-1]], stanford_success)
 
 
 def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscenes"):
@@ -448,4 +471,4 @@ def localize_omniscenes(cfg, writer=None, log_dir="./log", root="./data/omniscen
     return _run_dataset(cfg, writer, log_dir, filenames, per_image, "omniscenes_results.csv",
                         ["pano_name", "gt_trans", "gt_rot", "skipped?", "OmniLoc_trans", "OmniLoc_rot", "t_error (m)", "r_error (degrees)",
                          "time (s)"],
-                        lambda f: ["{}/{}".format(f.split("/")[-2], f.split("/")[-1])])
+                        lambda f: ["{}/{}".format(f.split("/")[-2], f.split("/")[-1])], omniscenes_success)
