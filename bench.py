@@ -11,16 +11,26 @@ every rank refines `steps` images); the only collective is the final all_gather 
     python bench.py                                   # 1 GPU, cfg2 (1M points, 2048x1024, 32 candidates)
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
 
-The JSON line carries both launch modes and both roofs:
+The JSON line:
   value / ms_per_step         default mode: 256 // B query images share one launch chain (cfg 4's shape on one GPU)
   single_image {...}          the literal cfg-2 mode: ONE query image per launch chain (B poses per launch)
-  roofline {...}              SURVEY.md 8(d): ALGORITHMIC bytes (24 B x points x poses) / kernel time vs the 8 TB/s HBM peak,
-                              kernel time measured live with HIP events; `traffic` = memory-side bytes per launch from the
-                              rocprofv3 PMC passes of THIS launch shape (profiles/roofs.json), null for any other shape;
-    roofline.hbm_measured     those measured bytes over the measured kernel time: the bandwidth the kernel really draws
-    roofline.valu             the roof that actually binds (the cloud and the panorama are cache resident): VALU instructions
-                              per point-pose and the VALU-busy fraction, from the same PMC passes; issue_frac_live = those
-                              instructions over this run's launch time against 1 instruction / SIMD / 4 cycles at 2400 MHz
+  roofline {...}              the roof that BINDS the dominant kernel: VALU issue.  The cloud and the panorama are L2 /
+                              Infinity-Cache resident (memory-side traffic = 5 % of the HBM peak), so SURVEY.md 8(d)'s
+                              algorithmic-bytes figure has saturated (> 1.0) and says nothing about the kernel any more;
+                              it is kept as roofline.algorithmic_hbm.
+    bound "valu"              achieved = wave64 VALU instructions per second = (instructions per point-pose from the rocprofv3
+                              PMC passes of THIS launch shape and THIS library build, profiles/roofs.json) x point-poses per
+                              launch / 64 / (this run's average launch time, HIP events minus the measured cost of an empty
+                              event pair); peak = 1024 SIMDs x 2400 MHz / 4 cycles per wave64 instruction.
+                              profiles/roofs.json entries carry pcl_source_hash() of the library they were collected from; if
+                              the loaded library differs, valu is null and the line falls back to bound "hbm" (algorithmic).
+    roofline.traffic          memory-side bytes per launch from the same PMC passes (2 x FETCH_SIZE + WRITE_SIZE)
+  also {...}                  measured in the same run (N = 1 only, --no-also skips): cfg 3, cfg 5, the reference's shipped
+                              shape (167k points x 6 candidates; 1 and 8 images per launch chain) and the whole per-image
+                              pipeline (make_input + refinement: what the reference's `time (s)` column measures,
+                              localize.py:208,222-223) at cfg-2 size
+  cpu_baseline {...}          the C oracle (oracle/pcl_oracle.c compiled with OpenMP: a PORT of the reference's loss +
+                              autograd, pinned to the reference by tests/golden) on the host cores
 """
 import argparse
 import json
@@ -43,10 +53,18 @@ WORKLOADS = {
     "cfg3": (1_000_000, 1024, 2048, 256, True),
     "cfg4": (1_000_000, 1024, 2048, 32, True),      # 64 query images in all, sharded over the ranks (steps = 64 / world)
     "cfg5": (10_000_000, 2048, 4096, 32, True),
+    "shipped": (166_667, 1024, 2048, 6, True),      # the reference's stanford_parallel.ini: 1M points / sample_rate 6, num_input 6
 }
 NUM_ITER, LR, PATIENCE, FACTOR, QUANTILE = 100, 0.1, 5, 0.8, 0.05
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_POINT_POSE = 24      # xyz + rgb fp32 read once per pose evaluation
+VALU_PEAK_GINSTR = 1024 * 2.4e9 / 4.0 / 1e9     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2400 MHz
+FMT_NAMES = {_lib.PANO_U8: "u8", _lib.PANO_F16: "f16", _lib.PANO_F32: "f32"}
+# the candidate grid of the reference's Stanford configs (75 translations x 24 rotations = 1800 poses on the box room)
+STANFORD_INIT = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_roll=2 * np.pi, min_roll=0, z_prior=None,
+                     sample_rate_for_init=None, trans_init_mode="quantile", x_max=None, x_min=None, y_max=None, y_min=None,
+                     z_max=None, z_min=None, num_split_h=4, num_split_w=4, xy_only=False, num_trans=50, yaw_only=False, num_yaw=4,
+                     num_pitch=4, num_roll=4, dataset="Stanford2D-3D-S")
 
 
 def usable_cores():
@@ -100,21 +118,304 @@ def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=12.0):
     pose_evals_per_s = n_pose / dt
     plumbing = cpu_cfg1_end_to_end(cores)
     return {"value": pose_evals_per_s / NUM_ITER, "unit": "candidate-poses/s", "cores": cores, "kind": "port",
+            "kind_is": "the oracle itself: oracle/pcl_oracle.c (scalar C restatement of the reference's loss + autograd, pinned to the "
+                       "reference's outputs by tests/golden) compiled with OpenMP; not the reference's torch code",
             "cfg1_end_to_end": plumbing,
             "sample": "%d fused loss+gradient pose evaluations over the full %d-point cloud (%.1f s), fp32 oracle/pcl_oracle.c "
                       "with OpenMP; one candidate = %d evaluations" % (n_pose, len(xyz), dt, NUM_ITER),
             "pose_evals_per_s": pose_evals_per_s}
 
 
-def lookup_roofs(path, workload, poses_per_launch, fmt_name):
+def lookup_roofs(path, workload, poses_per_launch, fmt_name, lib_hash):
     """Counter-derived figures for exactly this launch shape (profiles/roofs.json, written by profiles/summarize.py from
-    the rocprofv3 --pmc passes); None when the run's shape was never profiled."""
+    the rocprofv3 --pmc passes).  -> (key, entry or None, why-not or None).  An entry collected from a library whose loss
+    kernel sources differ from the loaded library's (pcl_source_hash) is NOT returned: a stale instruction count must not
+    be scored."""
     workload = {"cfg4": "cfg2"}.get(workload, workload)      # cfg 4 = cfg 2's cloud, panorama size and candidates per image
     key = "%s/poses%d/%s" % (workload, poses_per_launch, fmt_name)
     try:
-        return key, json.load(open(path)).get(key)
+        entry = json.load(open(path)).get(key)
     except Exception:
-        return key, None
+        return key, None, "no roofs file"
+    if entry is None:
+        return key, None, "launch shape never profiled"
+    if entry.get("source_hash") != lib_hash:
+        return key, None, "stale: profiled library %s, loaded library %s" % (entry.get("source_hash"), lib_hash)
+    return key, entry, None
+
+
+class Ranks:
+    """The process group of the run (None for one process): barrier, the result gather, MAX over ranks."""
+
+    def __init__(self, args, dev_holder):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, self.world, args.gpus))
+        # (PCL_DIST_BACKEND=gloo lets several ranks share one GPU: used by the test-suite to run the N > 1 code path end to
+        #  end on a single-GPU box; the driver's multi-GPU runs use the default, RCCL, one GPU per rank)
+        self.backend = os.environ.get("PCL_DIST_BACKEND", "nccl")
+        self.n_dev = torch.cuda.device_count()
+        if self.n_dev < 1:
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.device_count() == 0")
+        if self.backend == "nccl" and self.n_dev < args.gpus:
+            raise SystemExit("--gpus %d but only %d GPU(s) are visible to this process (torch.cuda.device_count()): one rank per "
+                             "GPU is required for the RCCL run" % (args.gpus, self.n_dev))
+        dev_index = local_rank % self.n_dev if self.backend != "nccl" else local_rank
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        self.dist = None
+        if self.world > 1 or os.environ.get("PCL_BENCH_FORCE_DIST") == "1":   # (the env knob exercises the RCCL path at world size 1)
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)     # RCCL
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.coll_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather(self, rows):
+        """the path's only collective: every rank's result rows (RCCL all_gather; gloo in the CPU tests)"""
+        if self.dist is None:
+            return rows
+        src = rows.contiguous() if self.backend == "nccl" else rows.cpu()
+        out = torch.empty(self.world * src.shape[0], src.shape[1], device=src.device)
+        self.dist.all_gather_into_tensor(out, src)
+        return out
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], device=self.coll_dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def agree(self, flag):
+        """rank 0's decision, on every rank"""
+        if self.dist is None:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], device=self.coll_dev)
+        self.dist.broadcast(t, src=0)
+        return bool(int(t.item()))
+
+
+class Scene:
+    """One synthetic room resident in HBM: the packed cloud (replicated on every rank), its quantile box, and packed query
+    panoramas / starting poses per image id, made on demand (untimed set-up)."""
+
+    def __init__(self, N, H, W, dev):
+        self.N, self.H, self.W, self.dev = N, H, W, dev
+        self.xyz, self.rgb = synth.box_room(N, seed=0)
+        self.X, self.C = torch.from_numpy(self.xyz).to(dev), torch.from_numpy(self.rgb).to(dev)
+        self.cloud = ops.Cloud(self.X, self.C)
+        self.box = ops.quantile_box(self.X, QUANTILE)
+        self._img = {}
+
+    def image(self, image_id, keep_img=False):
+        """-> dict(pano, gt=(t, ypr), img (device tensor, only if keep_img))"""
+        e = self._img.get(image_id)
+        if e is None or (keep_img and "img" not in e):
+            t_gt, ypr_gt = synth.gt_pose(image_id)
+            cam = ops.transform_cloud(self.X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
+            img = synth.quantise_like_image_file(ops.make_pano(cam, self.C, (self.H, self.W)))   # uint8-quantised like a decoded image file
+            e = {"pano": ops.Pano(img), "gt": (t_gt, ypr_gt)}
+            if keep_img:
+                e["img"] = img
+            self._img[image_id] = e
+        return e
+
+    def starts(self, image_id, B):
+        t_gt, ypr_gt = self.image(image_id)["gt"]
+        tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=image_id)
+        return torch.from_numpy(tr).to(self.dev), torch.from_numpy(ro).to(self.dev), (tr, ro)
+
+
+def equal_groups(K, B, H, W, requested=0):
+    """Images per launch chain.  auto: about 256 poses per launch, in EQUAL groups when the step count allows it (every timed
+    launch then has one shape, the one the counter passes under profiles/ were taken for): the largest divisor of K that is at
+    most 256 // B and at least half of it; otherwise groups of 256 // B with a shorter last one — and no more images than keep
+    their packed panoramas (8 B per texel) within ~half of the 256 MiB Infinity Cache: cfg 5's 4096x2048 panoramas are 67 MB each
+    (measured 330 / 328 / 312 candidate-poses/s at 1 / 2 / 4 images per launch), cfg 2's 16.8 MB (3260 / 3314 / 3295 at 4 / 8 / 16)."""
+    if requested > 0:
+        return max(1, min(requested, K))
+    cache_cap = max(1, int(140e6 // ((H + 2) * (W + 2) * 8)))
+    target = max(1, min(256 // B, K, cache_cap))
+    divs = [d for d in range(target, 0, -1) if K % d == 0 and 2 * d >= target]
+    return divs[0] if divs else target
+
+
+class Measure:
+    """Timed refinement of image ids `timed` (this rank's) of `scene` with B candidates each, `ipl` images per launch chain."""
+
+    def __init__(self, scene, B, batch_mode, ranks, timer_stride):
+        self.scene, self.B, self.batch_mode, self.ranks = scene, B, batch_mode, ranks
+        self.stride = max(1, timer_stride)
+        self.timed_per_run = len(range(0, NUM_ITER, self.stride))
+        self.gd_by_size = {}
+        self.cols = torch.tensor([0, 1, 2, 3, 4, 5, 12], device=scene.dev)
+
+    def prepare(self, image_ids, ipl, row0=0):
+        """launch groups of `ipl` images: (result rows, image ids, trans, rot, panorama table)"""
+        sc, B, out = self.scene, self.B, []
+        for s0 in range(0, len(image_ids), ipl):
+            grp = image_ids[s0:s0 + ipl]
+            m = len(grp)
+            if m not in self.gd_by_size:
+                tr0, ro0, _ = sc.starts(grp[0], B)
+                self.gd_by_size[m] = ops.GradientDescent(sc.cloud, sc.image(grp[0])["pano"], tr0.repeat(m, 1), ro0.repeat(m, 1), sc.box,
+                                                         lr=LR, patience=PATIENCE, factor=FACTOR, batch_mode=self.batch_mode)
+            st = [sc.starts(i, B) for i in grp]
+            tr = torch.cat([s[0] for s in st]).contiguous()
+            ro = torch.cat([s[1] for s in st]).contiguous()
+            table = torch.tensor([sc.image(i)["pano"].data.data_ptr() for i in grp for _ in range(B)], dtype=torch.int64, device=sc.dev)
+            out.append((list(range(row0 + s0, row0 + s0 + m)), grp, tr, ro, table))
+        return out
+
+    def refine(self, item, results, tm=None):
+        rows, grp, tr, ro, table = item
+        gd = self.gd_by_size[len(grp)]
+        gd.reset(tr, ro)
+        gd.set_pano_table(table)
+        gd.run(NUM_ITER, timer=tm)
+        res = gd.result().reshape(len(grp), self.B, -1)
+        k = torch.argmin(res[:, :, 12], dim=1)             # per image: smallest loss of the last forward
+        win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]
+        results[rows[0]:rows[-1] + 1, :7] = win.index_select(1, self.cols)
+
+    def timed_pass(self, items, results, K, tm, with_gather):
+        """EXACTLY K steps: barrier + synchronize, refine every timed image once (+ the result gather), synchronize +
+        barrier; returns the MAX over ranks of the elapsed wall time."""
+        if tm is not None:
+            tm.reset()
+        torch.cuda.synchronize()
+        self.ranks.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in items:
+            self.refine(it, results, tm)
+        if with_gather:
+            self.ranks.gather(results[:K])
+        torch.cuda.synchronize()
+        self.ranks.barrier()
+        torch.cuda.synchronize()
+        return self.ranks.max_over_ranks(time.perf_counter() - t0)
+
+    def repeated(self, items, results, K, tm, min_seconds, with_gather=True):
+        """timed passes until `min_seconds` of measurement (the count is agreed between ranks: rank 0's clock decides);
+        returns the list of pass times, the median pass and the kernel-timer reading of that pass"""
+        times, kernels, total = [], [], 0.0
+        while True:
+            dt = self.timed_pass(items, results, K, tm, with_gather)
+            times.append(dt)
+            kernels.append(tm.read() if tm is not None else (0.0, 0))
+            total += dt
+            if not self.ranks.agree(total < min_seconds and len(times) < 200):
+                break
+        mid = int(np.argsort(times)[len(times) // 2])
+        return times, times[mid], kernels[mid]
+
+
+def kernel_figures(N, B, groups, timed_per_run, kernel_ms, launches, pair_ms):
+    """Live loss-kernel figures of one measurement: average launch time (HIP events on the launch stream, minus what an empty
+    event pair reads) and SURVEY.md 8(d)'s algorithmic bytes over it."""
+    raw = kernel_ms / max(launches, 1)
+    avg = max(raw - pair_ms, 1e-6)
+    total_bytes = sum(BYTES_PER_POINT_POSE * N * B * len(g) * timed_per_run for g in groups)
+    alg_bytes = total_bytes / max(launches, 1)              # mean algorithmic bytes per timed launch
+    return {"avg_launch_ms": avg, "avg_launch_ms_raw": raw, "event_pair_ms": pair_ms, "launches_timed": launches,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBs": alg_bytes / (avg * 1e-3) / 1e9}
+
+
+def valu_roof(roofs, N, poses_per_launch, avg_launch_ms):
+    """The binding roof: wave64 VALU instructions per second of this run against one instruction per SIMD per 4 cycles."""
+    wave_instr = roofs["valu_instr_per_point_pose"] * N * poses_per_launch / 64.0
+    achieved = wave_instr / (avg_launch_ms * 1e-3) / 1e9
+    return {"achieved": achieved, "peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instr/s", "frac": achieved / VALU_PEAK_GINSTR,
+            "instr_per_point_pose": roofs["valu_instr_per_point_pose"], "wave_instr_per_launch": wave_instr,
+            "busy_frac_profiled": roofs.get("valu_busy_frac"), "source": roofs.get("source"), "source_hash": roofs.get("source_hash")}
+
+
+def run_side(name, ranks, args, lib_hash, pair_ms, timer_stride, scenes, K, ipl, min_seconds=0.6):
+    """One entry of the `also` block: workload `name` measured like the headline (distinct warm-up group, repeated timed
+    passes, kernel timer), shorter.  -> dict"""
+    N, H, W, B, batch_mode = WORKLOADS[name]
+    key = (N, H, W)
+    if key not in scenes:
+        scenes[key] = Scene(N, H, W, ranks.dev)
+    sc = scenes[key]
+    m = Measure(sc, B, batch_mode, ranks, timer_stride)
+    timed = list(range(K))
+    warm = [1_000_000 + i for i in range(ipl)]
+    items, witems = m.prepare(timed, ipl), m.prepare(warm, ipl, row0=K)
+    results = torch.zeros(K + ipl, 16, device=sc.dev)
+    timer = ops.KernelTimer(m.timed_per_run * (K + 1), stride=m.stride)
+    m.refine(witems[0], results)
+    torch.cuda.synchronize()
+    times, elapsed, (kernel_ms, launches) = m.repeated(items, results, K, timer, min_seconds, with_gather=False)
+    groups = [it[1] for it in items]
+    kf = kernel_figures(N, B, groups, m.timed_per_run, kernel_ms, launches, pair_ms)
+    fmt = FMT_NAMES[sc.image(0)["pano"].fmt]
+    rkey, roofs, why = lookup_roofs(args.roofs_json, name, ipl * B, fmt, lib_hash)
+    res_host = results[:K].cpu().numpy()
+    errs = []
+    for i in range(K):
+        R = ops.rot_from_ypr(torch.from_numpy(res_host[i, 3:6]))[0].cpu().numpy()
+        gt = sc.image(i)["gt"]
+        errs.append(synth.pose_errors(res_host[i, :3], R, gt[0], synth.rot_from_ypr_np(gt[1])))
+    errs = np.array(errs)
+    out = {"workload": "%d points, %dx%d, %d candidates, %d image(s) per launch chain" % (N, W, H, B, ipl),
+           "value": B * K / elapsed, "unit": "candidate-poses/s", "ms_per_step": elapsed / K * 1e3, "steps": K, "passes": len(times),
+           "poses_per_launch": ipl * B, "texels": fmt, "avg_launch_ms": kf["avg_launch_ms"],
+           "us_per_iteration": elapsed / (K / ipl) / NUM_ITER * 1e6,
+           "algorithmic_hbm_frac": kf["algorithmic_GBs"] / HBM_PEAK_GBS,
+           "valu_frac": valu_roof(roofs, N, ipl * B, kf["avg_launch_ms"])["frac"] if roofs else None,
+           "roofs_key": rkey, "valu_unavailable": why,
+           "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1]))}
+    return out
+
+
+def pipeline_block(sc, n_images=3):
+    """The whole per-image pipeline at cfg-2 size through the product's call surface — what the reference's `time (s)` CSV column
+    measures (localize.py:208,222-223): make_input (1800-pose grid -> loss trim to 64 -> histogram trim to 32) + omniloc_batch
+    (32 candidates x 100 iterations); medians over `n_images` query images after one untimed image."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import utils
+
+    class Cfg:
+        lr, num_iter, patience, factor, out_of_room_quantile, num_input = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE, 32
+
+    rows = []
+    for j in range(n_images + 1):
+        e = sc.image(2_000_000 + j, keep_img=True)
+        img = e["img"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr, ro = utils.make_input(img, sc.X, sc.C, 32, STANFORD_INIT, "loss_histogram", 64)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = po.omniloc_batch(img, sc.X, sc.C, tr, ro, Cfg(), {})
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        te, re = synth.pose_errors(res[0].numpy(), res[1].numpy(), e["gt"][0], synth.rot_from_ypr_np(e["gt"][1]))
+        if j > 0:
+            rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, te, re))
+        del e["img"]
+    rows = np.array(rows)
+    return {"what": "per query image at cfg-2 size (1M points, 2048x1024): make_input (75 x 24 = 1800-pose grid -> 64 -> 32) + "
+                    "omniloc_batch (32 candidates x 100 iterations), medians over %d images" % n_images,
+            "make_input_ms": float(np.median(rows[:, 0])), "refine_ms": float(np.median(rows[:, 1])),
+            "total_ms": float(np.median(rows[:, 0] + rows[:, 1])),
+            "median_t_err_m": float(np.median(rows[:, 2])), "median_r_err_deg": float(np.median(rows[:, 3]))}
 
 
 def main():
@@ -125,6 +426,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-launch-chain pass")
+    ap.add_argument("--no-also", action="store_true", help="skip the `also` block (cfg 3, cfg 5, shipped shape, per-image pipeline)")
     ap.add_argument("--images-per-launch", type=int, default=0,
                     help="query images whose candidates share one launch chain (0 = auto: 256 // B, at most --steps); "
                          "they share the cloud, each candidate samples its own image's panorama")
@@ -140,36 +442,10 @@ def main():
                     help="per-launch-shape counter figures from the rocprofv3 PMC passes (profiles/collect.sh)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    # (PCL_DIST_BACKEND=gloo lets several ranks share one GPU: used by the test-suite to run the N > 1 code path end to
-    #  end on a single-GPU box; the driver's multi-GPU runs use the default, RCCL, one GPU per rank)
-    backend = os.environ.get("PCL_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if n_dev < 1:
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.device_count() == 0")
-    if backend == "nccl" and n_dev < args.gpus:
-        raise SystemExit("--gpus %d but only %d GPU(s) are visible to this process (torch.cuda.device_count()): one rank per "
-                         "GPU is required for the RCCL run" % (args.gpus, n_dev))
-    dev_index = local_rank % n_dev if backend != "nccl" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1 or os.environ.get("PCL_BENCH_FORCE_DIST") == "1":   # (the env knob exercises the RCCL path at world size 1)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)     # RCCL
-        else:
-            dist.init_process_group(backend)
-    _lib.load()
+    ranks = Ranks(args, None)
+    rank, world, dev = ranks.rank, ranks.world, ranks.dev
+    lib = _lib.load()
+    lib_hash = lib.pcl_source_hash().decode()
 
     N, H, W, B, batch_mode = WORKLOADS[args.workload]
     if args.workload == "cfg4":
@@ -179,204 +455,123 @@ def main():
     # Images are refined in groups of `ipl`: the group's ipl * B candidates go through ONE chain of launches (shared
     # cloud, per-candidate panorama pointer).  More poses per launch share each cloud chunk in L2 and amortise the
     # per-block costs; the candidates stay independent (own Adam / scheduler state), so per-image results are the same.
-    if args.images_per_launch > 0:
-        ipl = max(1, min(args.images_per_launch, K))
-    else:
-        # auto: about 256 poses per launch, in EQUAL groups when the step count allows it (every timed launch then has
-        # one shape, the one the counter passes under profiles/ were taken for): the largest divisor of K that is at most
-        # 256 // B and at least half of it; otherwise groups of 256 // B with a shorter last one
-        # ... and no more images than keep their packed panoramas (8 B per texel) within ~half of the 256 MiB Infinity
-        # Cache: cfg 5's 4096x2048 panoramas are 67 MB each (measured 330 / 328 / 312 candidate-poses/s at 1 / 2 / 4 images
-        # per launch), cfg 2's 16.8 MB (3260 / 3314 / 3295 at 4 / 8 / 16)
-        cache_cap = max(1, int(140e6 // ((H + 2) * (W + 2) * 8)))
-        target = max(1, min(256 // B, K, cache_cap))
-        divs = [d for d in range(target, 0, -1) if K % d == 0 and 2 * d >= target]
-        ipl = divs[0] if divs else target
+    ipl = equal_groups(K, B, H, W, args.images_per_launch)
     # warm-up steps refine their OWN images (ids beyond every rank's timed ones), in whole launch groups of the timed size
     n_warm = ((Wm + ipl - 1) // ipl) * ipl if Wm > 0 else 0
     # (the untimed clock pre-warm needs a launch group of its own images even with --warmup 0)
-    n_img = K + max(n_warm, ipl if args.prewarm_ms > 0 else 0)
+    n_extra = max(n_warm, ipl if args.prewarm_ms > 0 else 0)
 
     # ---- untimed setup: synthetic room, one panorama per query image, everything packed and resident in HBM
-    xyz, rgb = synth.box_room(N, seed=0)                      # the shared cloud, replicated on every rank
-    X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
-    cloud = ops.Cloud(X, C)
-    box = ops.quantile_box(X, QUANTILE)
-    panos, starts, gts = [], [], []
-    for i in range(n_img):
-        # timed image i of this rank is query image rank + i * world (round-robin sharding); warm-up images follow
-        image_id = rank + i * world if i < K else 1_000_000 + rank + (i - K) * world
-        t_gt, ypr_gt = synth.gt_pose(image_id)
-        cam = ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
-        img = synth.quantise_like_image_file(ops.make_pano(cam, C, (H, W)))      # uint8-quantised like a decoded image file
-        panos.append(ops.Pano(img))
-        tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=image_id)
-        starts.append((torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev)))
-        gts.append((t_gt, ypr_gt))
-        if i == 0 and rank == 0:
-            img0_host, start0_host = img.cpu().numpy(), (tr, ro)
-        del cam, img
-    fmt_name = {_lib.PANO_U8: "u8", _lib.PANO_F16: "f16", _lib.PANO_F32: "f32"}[panos[0].fmt]
-    results = torch.zeros(n_img, 16, device=dev)
+    scenes = {(N, H, W): Scene(N, H, W, dev)}
+    sc = scenes[(N, H, W)]
+    # timed image i of this rank is query image rank + i * world (round-robin sharding); warm-up images follow
+    timed_ids = [rank + i * world for i in range(K)]
+    warm_ids = [1_000_000 + rank + i * world for i in range(n_extra)]
+    if rank == 0:
+        e0 = sc.image(timed_ids[0], keep_img=True)
+        img0_host = e0.pop("img").cpu().numpy()
+        start0_host = sc.starts(timed_ids[0], B)[2]
+    for i in timed_ids + warm_ids:
+        sc.image(i)
+    fmt_name = FMT_NAMES[sc.image(timed_ids[0])["pano"].fmt]
+    results = torch.zeros(K + n_extra, 16, device=dev)
     # HIP-event pairs around every TIMER_STRIDE-th loss launch of the timed region (each pair costs a few us of GPU
     # timeline; bracketing all 100 launches of a refinement slows cfg 1 by 2x and cfg 2 by ~2 %)
-    timed_per_run = len(range(0, NUM_ITER, max(1, args.timer_stride)))
-    timer = ops.KernelTimer(timed_per_run * (K + 1), stride=args.timer_stride)
-    cols = torch.tensor([0, 1, 2, 3, 4, 5, 12], device=dev)
+    m = Measure(sc, B, batch_mode, ranks, args.timer_stride)
+    timer = ops.KernelTimer(m.timed_per_run * (K + 1), stride=m.stride)
 
-    def make_groups(images, per):
-        return [images[s0:s0 + per] for s0 in range(0, len(images), per)]
-
-    gd_by_size = {}
-
-    def prepare(groups):
-        out = []
-        for grp in groups:
-            m = len(grp)
-            if m not in gd_by_size:
-                gd_by_size[m] = ops.GradientDescent(cloud, panos[0], starts[0][0].repeat(m, 1), starts[0][1].repeat(m, 1), box, lr=LR,
-                                                    patience=PATIENCE, factor=FACTOR, batch_mode=batch_mode)
-            tr = torch.cat([starts[i][0] for i in grp]).contiguous()
-            ro = torch.cat([starts[i][1] for i in grp]).contiguous()
-            table = torch.tensor([panos[i].data.data_ptr() for i in grp for _ in range(B)], dtype=torch.int64, device=dev)
-            out.append((grp, tr, ro, table))
-        return out
-
-    def refine(item, tm=None):
-        grp, tr, ro, table = item
-        gd = gd_by_size[len(grp)]
-        gd.reset(tr, ro)
-        gd.set_pano_table(table)
-        gd.run(NUM_ITER, timer=tm)
-        res = gd.result().reshape(len(grp), B, -1)
-        k = torch.argmin(res[:, :, 12], dim=1)             # per image: smallest loss of the last forward
-        win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]
-        results[grp[0]:grp[-1] + 1, :7] = win.index_select(1, cols)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    def gather_results():
-        """the path's only collective: every rank's result rows (RCCL all_gather; gloo in the CPU tests)"""
-        if dist is None:
-            return results[:K]
-        src = results[:K].contiguous() if backend == "nccl" else results[:K].cpu()
-        out = torch.empty(world * K, 16, device=src.device)
-        dist.all_gather_into_tensor(out, src)
-        return out
-
-    def timed_pass(items, tm, with_gather):
-        """EXACTLY K steps: barrier + synchronize, refine every timed image once (+ the result gather), synchronize +
-        barrier; returns the MAX over ranks of the elapsed wall time."""
-        if tm is not None:
-            tm.reset()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for it in items:
-            refine(it, tm)
-        if with_gather:
-            gather_results()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
-        return elapsed
-
-    def repeated(items, tm, with_gather):
-        """timed passes until --min-seconds of measurement (the count is agreed between ranks: rank 0's clock decides);
-        returns the list of pass times and the kernel-timer reading of the median pass"""
-        times, kernels, total = [], [], 0.0
-        while True:
-            dt = timed_pass(items, tm, with_gather)
-            times.append(dt)
-            kernels.append(tm.read() if tm is not None else (0.0, 0))
-            total += dt
-            go = torch.tensor([1 if (total < args.min_seconds and len(times) < 200) else 0], device=dev if backend == "nccl" else "cpu")
-            if dist is not None:
-                dist.broadcast(go, src=0)
-            if not int(go.item()):
-                break
-        mid = int(np.argsort(times)[len(times) // 2])
-        return times, times[mid], kernels[mid]
-
-    timed_items = prepare(make_groups(list(range(K)), ipl))
-    warm_items = prepare(make_groups(list(range(K, n_img)), ipl))
+    timed_items = m.prepare(timed_ids, ipl)
+    warm_items = m.prepare(warm_ids, ipl, row0=K)
     if args.prewarm_ms > 0 and warm_items:                      # part of the untimed setup, not of the W warm-up steps
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            refine(warm_items[0])
+            m.refine(warm_items[0], results)
             torch.cuda.synchronize()
     for it in warm_items[:n_warm // ipl]:                      # the W warm-up steps (distinct images)
-        refine(it)
-    if dist is not None:                                       # first use of the collective sets up its connections: untimed
-        gather_results()
+        m.refine(it, results)
+    if ranks.dist is not None:                                 # first use of the collective sets up its connections: untimed
+        ranks.gather(results[:K])
+    torch.cuda.synchronize()
+    pair_ms = timer.calibrate(64)                              # what an event pair reads with nothing in between
     results[:, 14] = float(rank)                                # stamp: which rank produced the row
-    pass_times, elapsed, (kernel_ms, launches) = repeated(timed_items, timer, True)
+    pass_times, elapsed, (kernel_ms, launches) = m.repeated(timed_items, results, K, timer, args.min_seconds)
     # proof that the collective really spanned N ranks: distinct rank stamps among the gathered rows
-    ranks_seen = int(torch.unique(gather_results()[:, 14]).numel())
+    ranks_seen = int(torch.unique(ranks.gather(results[:K])[:, 14]).numel())
 
     # accuracy of this rank's images (localize.py:239-247 formulas)
     errs = []
     res_host = results[:K].cpu().numpy()
     for i in range(K):
         R = ops.rot_from_ypr(torch.from_numpy(res_host[i, 3:6]))[0].cpu().numpy()
-        errs.append(synth.pose_errors(res_host[i, :3], R, gts[i][0], synth.rot_from_ypr_np(gts[i][1])))
+        gt = sc.image(timed_ids[i])["gt"]
+        errs.append(synth.pose_errors(res_host[i, :3], R, gt[0], synth.rot_from_ypr_np(gt[1])))
     errs = np.array(errs)
 
     # ---- the literal cfg-2 mode: ONE query image per launch chain (B poses per launch), same images, same protocol
     single = None
     if not args.no_single_image and ipl > 1:
-        single_items = prepare(make_groups(list(range(K)), 1))
-        refine(prepare(make_groups([K], 1))[0] if n_img > K else single_items[0])       # untimed: first launch of this grid shape
-        s_times, s_elapsed, (s_kernel_ms, s_launches) = repeated(single_items, timer, True)
-        s_bytes = BYTES_PER_POINT_POSE * N * B * s_launches
+        single_items = m.prepare(timed_ids, 1)
+        m.refine(m.prepare(warm_ids[:1], 1, row0=K)[0] if warm_ids else single_items[0], results)   # untimed: first launch of this grid shape
+        s_times, s_elapsed, (s_kernel_ms, s_launches) = m.repeated(single_items, results, K, timer, args.min_seconds)
+        s_kf = kernel_figures(N, B, [it[1] for it in single_items], m.timed_per_run, s_kernel_ms, s_launches, pair_ms)
+        s_key, s_roofs, s_why = lookup_roofs(args.roofs_json, args.workload, B, fmt_name, lib_hash)
         single = {"value": B * K * world / s_elapsed, "ms_per_step": s_elapsed / K * 1e3, "images_per_launch": 1,
                   "poses_per_launch": B, "passes": len(s_times),
-                  "roofline_achieved_GBs": s_bytes / (s_kernel_ms * 1e-3) / 1e9,
-                  "frac": s_bytes / (s_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "avg_launch_ms": s_kernel_ms / max(s_launches, 1), "launches_timed": s_launches}
+                  "valu_frac": valu_roof(s_roofs, N, B, s_kf["avg_launch_ms"])["frac"] if s_roofs else None,
+                  "valu_unavailable": s_why, "roofs_key": s_key,
+                  "algorithmic_hbm_frac": s_kf["algorithmic_GBs"] / HBM_PEAK_GBS,
+                  "avg_launch_ms": s_kf["avg_launch_ms"], "launches_timed": s_launches,
+                  "kernel_ms_per_step": NUM_ITER * s_kf["avg_launch_ms"]}
 
+    line = None
     if rank == 0:
         value = B * K * world / elapsed
-        per_launch_ms = kernel_ms / max(launches, 1)
-        groups = [it[0] for it in timed_items]
-        # a launch of group g evaluates len(g) images x B candidates; every run times the same number of launches
-        total_bytes = sum(BYTES_PER_POINT_POSE * N * B * len(g) * timed_per_run for g in groups)
-        assert launches == timed_per_run * len(groups), (launches, timed_per_run, len(groups))
-        alg_bytes = total_bytes / max(launches, 1)              # mean algorithmic bytes per timed launch
-        achieved = total_bytes / (kernel_ms * 1e-3) / 1e9
-        # counter-derived figures exist per launch SHAPE (workload, poses per launch, texel format); a run of any other
-        # shape reports null rather than another shape's numbers
+        groups = [it[1] for it in timed_items]
+        assert launches == m.timed_per_run * len(groups), (launches, m.timed_per_run, len(groups))
+        kf = kernel_figures(N, B, groups, m.timed_per_run, kernel_ms, launches, pair_ms)
+        # counter-derived figures exist per launch SHAPE (workload, poses per launch, texel format) and per library build;
+        # a run of any other shape, or of a library with other loss-kernel sources, reports null rather than another's numbers
         uniform = len({len(g) for g in groups}) == 1
-        roofs_key, roofs = lookup_roofs(args.roofs_json, args.workload, len(groups[0]) * B, fmt_name) if uniform else ("mixed launch shapes", None)
+        if uniform:
+            roofs_key, roofs, why = lookup_roofs(args.roofs_json, args.workload, len(groups[0]) * B, fmt_name, lib_hash)
+        else:
+            roofs_key, roofs, why = "mixed launch shapes", None, "mixed launch shapes"
         traffic = roofs.get("hbm_bytes_per_launch") if roofs else None
         hbm_measured = None
         if traffic:
-            hbm_measured = {"bytes_per_launch": traffic, "GBs": traffic / (per_launch_ms * 1e-3) / 1e9,
-                            "frac_of_peak": traffic / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            hbm_measured = {"bytes_per_launch": traffic, "GBs": traffic / (kf["avg_launch_ms"] * 1e-3) / 1e9,
+                            "frac_of_peak": traffic / (kf["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) of this launch "
                                     "shape over this run's kernel time: the cloud and the panorama are cache resident, HBM is idle"}
-        valu = None
+        algorithmic = {"achieved": kf["algorithmic_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kf["algorithmic_GBs"] / HBM_PEAK_GBS,
+                       "bytes_per_launch": kf["algorithmic_bytes_per_launch"], "saturated": kf["algorithmic_GBs"] / HBM_PEAK_GBS > 0.9,
+                       "is": "SURVEY.md 8(d)'s ALGORITHMIC figure: 24 B x points x poses per launch / kernel time.  Not a bandwidth and no "
+                             "longer a roof: a block reads its cloud chunk once for the two poses it evaluates, out of L2, so the figure "
+                             "can pass 1.0 while the measured memory-side traffic is ~5 % of the HBM peak"}
+        kernel_name = "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if (B * ipl) % 2 == 0 else 1, {"u8": "RGBA8", "f16": "F16x4", "f32": "F32x4"}[fmt_name])
+        common = {"kernel": kernel_name, "traffic": traffic, "traffic_key": roofs_key,
+                  "avg_launch_ms": kf["avg_launch_ms"], "avg_launch_ms_raw_events": kf["avg_launch_ms_raw"],
+                  "event_pair_ms_subtracted": pair_ms, "launches_timed": launches,
+                  "algorithmic_hbm": algorithmic, "hbm_measured": hbm_measured, "source_hash_loaded_library": lib_hash}
         if roofs and roofs.get("valu_instr_per_point_pose"):
-            # live VALU-issue figure: this run's kernel time against one wave64 VALU instruction per SIMD every 4 cycles
-            # at the guide's 2400 MHz maximum clock (256 CUs x 4 SIMDs) — counted instructions only: transcendentals,
-            # s_nop slots between dependent packed ops and clocks below the maximum all lower it
-            wave_instr = roofs["valu_instr_per_point_pose"] * N * B * len(groups[0]) / 64.0
-            issue_peak = 1024 * 2.4e9 / 4.0 * (per_launch_ms * 1e-3)
-            valu = {"instr_per_point_pose": roofs["valu_instr_per_point_pose"], "busy_frac": roofs["valu_busy_frac"],
-                    "issue_frac_live": wave_instr / issue_peak,
-                    "issue_frac_is": "profiled wave64 VALU instructions per launch / (1024 SIMDs x 2400 MHz / 4 cycles x this run's "
-                                     "average launch time)",
-                    "source": roofs.get("source"),
-                    "note": "wave64 VALU instructions per 64 point-poses and 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): "
-                            "the kernel is VALU-issue bound, this is the roof with headroom left"}
+            v = valu_roof(roofs, N, len(groups[0]) * B, kf["avg_launch_ms"])
+            roofline = {"bound": "valu", "achieved": v["achieved"], "peak": v["peak"], "unit": v["unit"], "frac": v["frac"],
+                        "bound_is": "VALU issue: wave64 VALU instructions per launch (rocprofv3 SQ_INSTS_VALU of this launch shape and this "
+                                    "library build) / this run's launch time, against 1024 SIMDs x 2400 MHz / 4 cycles per instruction; "
+                                    "transcendentals (8-cycle issue), the s_nop slots between dependent packed ops and clocks below 2400 MHz "
+                                    "all lower it",
+                        "valu": v}
+        else:
+            roofline = {"bound": "hbm", "achieved": algorithmic["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic["frac"],
+                        "bound_is": "FALLBACK to the algorithmic-bytes figure: no VALU instruction count for this launch shape from this "
+                                    "library build (%s); the kernel is VALU-issue bound, see profiles/" % why,
+                        "valu": None}
+        roofline.update(common)
+        # consistency of the line with itself: the loss kernel's time inside one step cannot exceed the step
+        kernel_ms_per_step = NUM_ITER * kf["avg_launch_ms"] / ipl
+        checks = {"kernel_ms_per_step": kernel_ms_per_step, "ms_per_step": elapsed / K * 1e3,
+                  "kernel_time_within_step": bool(kernel_ms_per_step <= elapsed / K * 1e3),
+                  "kernel_share_of_step": kernel_ms_per_step / (elapsed / K * 1e3)}
         line = {
             "metric": "candidate-poses/s", "value": value, "unit": "candidate-poses/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -387,21 +582,31 @@ def main():
                        "mode": "omniloc_batch" if batch_mode else "omniloc", "images_per_launch": ipl,
                        "poses_per_launch": ipl * B, "texels": fmt_name, "warmup_images": "distinct from the timed ones"},
             "passes": len(pass_times), "pass_ms": {"min": min(pass_times) * 1e3, "median": elapsed * 1e3, "max": max(pass_times) * 1e3},
-            "ranks_seen": ranks_seen, "devices_visible": n_dev,
+            "ranks_seen": ranks_seen, "devices_visible": ranks.n_dev,
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
             "single_image": single,
-            "roofline": {"bound": "hbm", "kernel": "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if (B * ipl) % 2 == 0 else 1, {"u8": "RGBA8", "f16": "F16x4", "f32": "F32x4"}[fmt_name]),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate_6290GBs": achieved / 6290.0,
-                         "achieved_is": "ALGORITHMIC bytes (24 B x points x poses per launch, SURVEY.md 8d) / measured kernel time; "
-                                        "not a bandwidth: see hbm_measured and valu",
-                         "traffic": traffic, "traffic_key": roofs_key,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms, "launches_timed": launches,
-                         "hbm_measured": hbm_measured, "valu": valu},
+            "roofline": roofline,
+            "checks": checks,
         }
+        if not args.no_also and world == 1:
+            also = {}
+            t_also = time.perf_counter()
+            try:
+                if args.workload != "cfg3":
+                    also["cfg3"] = run_side("cfg3", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=1)
+                also["shipped_1_image_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=1)
+                also["shipped_8_images_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=8)
+                if (1_000_000, 1024, 2048) in scenes:
+                    also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
+                if args.workload != "cfg5":
+                    also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
+            except Exception as exc:                        # the headline must survive a failing side measurement
+                also["error"] = "%s: %s" % (type(exc).__name__, exc)
+            also["seconds"] = time.perf_counter() - t_also
+            line["also"] = also
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(xyz, rgb, img0_host, start0_host[0], start0_host[1])
+            line["cpu_baseline"] = cpu_baseline(sc.xyz, sc.rgb, img0_host, start0_host[0], start0_host[1])
     # RCCL prints its version banner through C stdio, which is flushed at exit — after Python's own output.  Every rank
     # flushes it now, before the last barrier, so that rank 0's JSON line is the last thing the job writes to stdout.
     try:
@@ -410,9 +615,9 @@ def main():
     except Exception:
         pass
     sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ranks.dist is not None:
+        ranks.dist.barrier()
+        ranks.dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
 

@@ -356,6 +356,13 @@ class KernelTimer:
         _lib.check(_lib.load().pcl_timer_read(self.handle, ctypes.byref(ms), ctypes.byref(cnt)), "pcl_timer_read")
         return ms.value, cnt.value
 
+    def calibrate(self, reps=64):
+        """Median reading (ms) of an event pair with NOTHING between its two records, on the current stream: what a pair around
+        a kernel over-reads.  Synchronises."""
+        ms = ctypes.c_double(0)
+        _lib.check(_lib.load().pcl_timer_calibrate(self.handle, int(reps), ctypes.byref(ms), _stream()), "pcl_timer_calibrate")
+        return ms.value
+
     def __del__(self):
         try:
             if self.handle:

@@ -12,9 +12,9 @@ TAG=${1:-r02}; shift || true
 if [ "${1:-}" = "--script" ]; then shift; CMD="$*"; PMC_CMD="$*"; else
   ARGS=${*:---workload ${WORKLOAD:-cfg2} --steps 8 --warmup 8 --no-cpu-baseline}
   # one launch shape per run: without the single-image pass the kernel-stats average IS the headline launch's duration
-  CMD="bench.py $ARGS --no-single-image"
+  CMD="bench.py $ARGS --no-single-image --no-also"
   # counter passes: one cold pass is enough (every dispatch is serialised by the counter reads), no warm-up steps
-  PMC_CMD="bench.py $ARGS --min-seconds 0 --no-single-image --warmup 0 --prewarm-ms 0"
+  PMC_CMD="bench.py $ARGS --min-seconds 0 --no-single-image --no-also --warmup 0 --prewarm-ms 0"
 fi
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -18,6 +18,16 @@ import sys
 from collections import defaultdict
 
 
+def library_hash():
+    """pcl_source_hash() of the library the profiled command loaded (host-only call): bench.py scores an entry only for a library
+    with the same loss-kernel sources."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "piccolo_amd", "lib", "libpiccolo_hip.so")
+    lib = ctypes.CDLL(os.environ.get("PCL_SO", so))
+    lib.pcl_source_hash.restype = ctypes.c_char_p
+    return lib.pcl_source_hash().decode()
+
+
 def short(name):
     return name.split("(")[0].replace("void ", "")[:70]
 
@@ -75,6 +85,7 @@ def main(d):
         cand = [r for k, r in roofs.items() if k.startswith("pcl_loss_kernel") and ", true," in k]
         if cand:
             best = dict(max(cand, key=lambda r: r.get("valu_insts_per_launch", 0)))
+            best["source_hash"] = library_hash()
             best["source"] = "profiles/%s (rocprofv3 --pmc passes of: %s)" % (os.environ.get("ROOF_SOURCE", os.path.basename(d.rstrip("/"))), os.environ.get("ROOF_CMD", "bench.py"))
             json.dump({key: best}, open(os.path.join(out, "roofs.json"), "w"), indent=1, sort_keys=True)
             print("roofs.json:", key, {n: best.get(n) for n in ("hbm_bytes_per_launch", "valu_instr_per_point_pose", "valu_busy_frac")})

@@ -248,13 +248,17 @@ def test_bench_rccl_path_at_world_size_one():
     import sys
     from conftest import REPO
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
-           "--no-cpu-baseline", "--min-seconds", "0.2"]
+           "--no-cpu-baseline", "--no-also", "--min-seconds", "0.2"]
     d = _run_bench(cmd, {"PCL_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29579"})
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["devices_visible"] >= 1 and d["value"] > 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    # cfg 1 at 2 poses per launch was never profiled with counters: the run must say so instead of borrowing numbers
+    # cfg 1 at 2 poses per launch was never profiled with counters: no VALU instruction count for this shape, so the line falls
+    # back to the algorithmic-bytes figure and says so instead of borrowing another shape's numbers
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "FALLBACK" in r["bound_is"]
     assert r["traffic"] is None and r["hbm_measured"] is None and r["valu"] is None and "cfg1" in r["traffic_key"]
+    assert abs(r["algorithmic_hbm"]["frac"] - r["frac"]) < 1e-12 and r["event_pair_ms_subtracted"] >= 0
+    assert r["avg_launch_ms"] <= r["avg_launch_ms_raw_events"] and len(r["source_hash_loaded_library"]) == 16
+    assert d["checks"]["kernel_time_within_step"] and "also" not in d
 
 
 def test_bench_refuses_more_ranks_than_gpus():
