@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate */
+#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_* */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -217,6 +217,23 @@ int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, in
  * up to its first empty block (utils.py:568-571), divided by nsh * nsw (utils.py:580). */
 int pcl_hist_trim_reduce(const float *inter, const int32_t *nproj, const int32_t *nimg, int ncand, int nsh, int nsw, float *score,
                          void *stream);
+/* First trimming stage of the initialisation, utils.py:462-507 trim_input_loss: the forward-only sampling loss
+ * (utils.py:484-499 = omniloc.py:171-202 without gradient) of ALL K x R pairs of trans [K][3] and rot [R][3] (yaw, pitch, roll),
+ * loss_table [K][R] row-major like the reference's `loss_table[i, j]` (utils.py:497; its argsort / index decode stay with the
+ * caller), count_table [K][R] (nullable) = points kept by the mask.  Rotations that differ only in YAW share the projection:
+ * with q' = RY(pitch) RX(roll) (x - t), theta does not depend on yaw and phi = atan2(q'_y, q'_x) + yaw - 1e-6 p_y / rho^2 (first
+ * order in the reference's `x + 1e-6`; points within 0.1 mm of the camera's vertical axis are evaluated exactly), so a block
+ * rotates a point and takes both atan2s once for up to four yaws.
+ *   pcl_trim_groups: classes of equal (pitch, roll) of the rotation table (bitwise), built on the device into
+ *     `groups` (pcl_trim_groups_bytes(R) bytes; its first int32 is the number of 4-yaw groups, which a caller may read back ONCE
+ *     per rotation grid and pass as `ngroups`; passing R is always valid: surplus blocks return at once).
+ *   pcl_trim_loss: workspace pcl_trim_loss_workspace_bytes(n, K, ngroups). */
+size_t pcl_trim_groups_bytes(int R);
+int pcl_trim_groups(const float *rot, int R, void *groups, void *stream);
+size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups);
+int pcl_trim_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans, int K,
+                  const float *rot, int R, const void *groups, int ngroups, float *loss_table, float *count_table,
+                  void *workspace, size_t workspace_bytes, void *stream);
 /* Scatter-min depth mask on the PACKED cloud for B poses (build-defined, off by default in the loss):
  * visible[b][i] = 1 iff point i (packed order) is within (1 + tau) of the nearest point that falls into the same
  * make_pano pixel (utils.py:158-165) of an H x W panorama seen from pose b.  Feeds the `visible` argument of

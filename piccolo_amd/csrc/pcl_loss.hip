@@ -265,6 +265,24 @@ size_t pcl_partials_bytes(int64_t n, int B)
 
 int pcl_plan_nchunks(int64_t n, int B) { return pcl_plan(n, B).nchunks; }
 
+// the same decomposition for a kernel with its own notion of a pose group (pcl_trim.hip: one block = one chunk x one
+// (translation, rotation class) slot): chunks, XCD runs and balanced steps as for `ngroups` groups of two poses
+void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int* steps_base, int* steps_rem)
+{
+    PclPlan p = pcl_plan(n, 2 * ngroups);
+    static const int chunks_env = pcl_env_int("PCL_TRIM_CHUNKS", 0);          // experiments
+    if (chunks_env >= 8) {
+        int64_t steps = (n + PCL_STEP - 1) / PCL_STEP, want = ((chunks_env + 7) / 8) * 8;
+        if (want > steps) want = ((steps + 7) / 8) * 8;
+        p.nchunks = (int)want; p.steps_base = (int)(steps / want); p.steps_rem = (int)(steps % want);
+        static const int runs_env = pcl_env_int("PCL_TRIM_RUNS", 0);
+        int cpx = p.nchunks / 8, runs = runs_env < 1 || runs_env > cpx ? cpx : runs_env;
+        while (cpx % runs) runs--;
+        p.seg_len = cpx / runs;
+    }
+    *nchunks = p.nchunks; *seg_len = p.seg_len; *steps_base = p.steps_base; *steps_rem = p.steps_rem;
+}
+
 template <int G, int FMT>
 static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
 {

@@ -1,0 +1,424 @@
+// pcl_trim.hip — trim_input_loss (utils.py:462-507): the forward-only sampling loss of ALL K x R (translation, rotation)
+// candidate pairs of the initialisation stage, with the projection shared between the rotations that differ only in yaw.
+//
+// The reference loops K * R forwards in Python (utils.py:484-499: p = R (x - t) -> cloud2idx -> sample_from_img -> mask ->
+// mean ||c - rgb||).  The candidate rotations are a GRID (utils.py:321-360): yaw x pitch x roll, R = RZ(yaw) RY(pitch) RX(roll).
+// For q' = RY RX (x - t):  p = RZ(yaw) q'  has  p_z = q'_z  and  p_x^2 + p_y^2 = q'_x^2 + q'_y^2, so
+//     theta = atan2(rho, p_z + eps)                    does not depend on yaw at all (panorama row and its fraction shared),
+//     phi   = atan2(p_y, p_x + eps) = phi0 + yaw - eps p_y / rho^2 + O(eps^2 / rho^2),   phi0 = atan2(q'_y, q'_x)
+// (first-order carry of the reference's `x + 1e-6`, utils.py:48-51; eps / rho < 1e-2 for every point farther than 0.1 mm from the
+// camera's vertical axis — waves that hold a nearer point evaluate phi exactly, see `tiny` below).  A block therefore rotates,
+// normalises and takes BOTH atan2s once per point for up to PCL_TRIM_Y yaws of one (pitch, roll) class and per yaw only
+// shifts the column, gathers and accumulates: measured VALU instructions per point-pose 78.5 (generic forward kernel) ->
+// see DESIGN.md §4.6.  configs of the reference: omniscenes.ini is yaw_only with 8 yaws (one class per translation), the
+// Stanford grids give 24 distinct rotations in classes of up to four yaws.
+//
+// Which rotations share: R_a and R_b differ by a yaw — R_b = RZ(delta) R_a — exactly when their THIRD ROWS are equal (RZ leaves
+// the z row alone).  Equal (pitch, roll) is the obvious case; the reference's 3-DoF grid of quarter turns (24 distinct rotations out
+// of 4 x 4 x 4, utils.py:338-360) falls into 6 such classes of 4 although only 8 of its 16 (pitch, roll) pairs repeat: e.g.
+// (0, pi, pi) = RZ(pi) (0, 0, 0).  Classes are found ON THE DEVICE from the (R, 3) rotation table (third rows, computed in double,
+// equal to 4e-7 — the table's quarter turns are fp32 roundings of pi/2, pi, ...: as matrices the grid's "equal" rotations differ by
+// 1e-7, which is also how far the fp32 rotation matrix the reference multiplies with is from the ideal one), the class's first rotation
+// supplies the matrix, every member its yaw relative to it (double).  The entry point takes the reference's arguments as they
+// are; pairs come back as the reference's row-major loss_table[i, j] (utils.py:497).
+#include <stdlib.h>
+
+#include "pcl_sample_device.h"
+
+#define PCL_TRIM_Y 4        // yaws evaluated per loaded point pair (partials row = PCL_TRIM_Y x {sum ||d||, count} = PCL_NACC floats)
+static_assert(2 * PCL_TRIM_Y == PCL_NACC, "a trim partials row has the size of a loss partials row");
+
+// One (pitch, roll) class of rotations, up to PCL_TRIM_Y of its yaws — read through scalar loads.
+struct PclTrimGroup {
+    float ns[PCL_TRIM_Y], nc[PCL_TRIM_Y]; // -sin / -cos of the member's yaw relative to the class's first rotation
+    float turn[PCL_TRIM_Y];               // 0.5 - yaw / 2 pi, that yaw reduced to [0, 2 pi): in (-0.5, 0.5]
+    int rot_idx[PCL_TRIM_Y];              // row of the rotation table
+    int ny;
+    int leader;                           // row of the class's first rotation (its matrix is the slot's pose record)
+    float row1[PCL_TRIM_Y][3];            // second row of the member's OWN fp32 rotation matrix (exact sign of p_y at the seam)
+    int pad[2];
+};
+static_assert(sizeof(PclTrimGroup) == 128, "trim group record");
+
+// blob handed back to the caller: header + PclTrimGroup[R]
+struct PclTrimHeader {
+    int ngroups, R;
+    int pad[30];
+};
+static_assert(sizeof(PclTrimHeader) == 128, "trim groups header");
+
+void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int* steps_base, int* steps_rem);
+
+// ---------------------------------------------------------------- classes of the rotation table (one block)
+// R = RZ(yaw) RY(pitch) RX(roll) in double from the fp32 angles
+__device__ inline void pcl_trim_rot_d(const float* ypr, double R[9])
+{
+    double sy, cy, sp, cp, sr, cr;
+    sincos((double)ypr[0], &sy, &cy);
+    sincos((double)ypr[1], &sp, &cp);
+    sincos((double)ypr[2], &sr, &cr);
+    R[0] = cy * cp; R[1] = cy * sp * sr - sy * cr; R[2] = cy * sp * cr + sy * sr;
+    R[3] = sy * cp; R[4] = sy * sp * sr + cy * cr; R[5] = sy * sp * cr - cy * sr;
+    R[6] = -sp;     R[7] = cp * sr;                R[8] = cp * cr;
+}
+
+__global__ void __launch_bounds__(256) pcl_trim_groups_kernel(const float* __restrict__ rot, int R, PclTrimHeader* hdr, PclTrimGroup* groups)
+{
+    extern __shared__ double shd[];              // zrow[3 R] doubles, then leader[R], pos[R], base[R] ints
+    double* zrow = shd;
+    int* leader = reinterpret_cast<int*>(shd + 3 * R);
+    int* pos = leader + R;
+    int* base = pos + R;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        double M[9];
+        pcl_trim_rot_d(rot + 3 * r, M);
+        zrow[3 * r] = M[6]; zrow[3 * r + 1] = M[7]; zrow[3 * r + 2] = M[8];
+    }
+    __syncthreads();
+    const double tol = 4e-7;
+    auto same = [&](int i, int j) {
+        return fabs(zrow[3 * i] - zrow[3 * j]) <= tol && fabs(zrow[3 * i + 1] - zrow[3 * j + 1]) <= tol && fabs(zrow[3 * i + 2] - zrow[3 * j + 2]) <= tol;
+    };
+    // leader = the first rotation with the same third row; it must be a leader itself (the relation is not transitive at the
+    // edge of the tolerance: a rotation only joins a class through the class's first member)
+    if (threadIdx.x == 0) {
+        for (int r = 0; r < R; r++) {
+            int l = r;
+            for (int j = 0; j < r; j++)
+                if (leader[j] == j && same(j, r)) { l = j; break; }
+            leader[r] = l;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        int p = 0;
+        for (int j = leader[r]; j < r; j++) p += leader[j] == leader[r];
+        pos[r] = p;
+    }
+    __syncthreads();
+    // sub-groups of PCL_TRIM_Y yaws: classes in the order of their first rotation
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        int b = 0;
+        if (leader[r] == r) {
+            for (int l = 0; l < r; l++) {
+                if (leader[l] != l) continue;
+                int size = 0;
+                for (int j = l; j < R; j++) size += leader[j] == l;
+                b += (size + PCL_TRIM_Y - 1) / PCL_TRIM_Y;
+            }
+        }
+        base[r] = b;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const int l = leader[r];
+        int size = 0;
+        for (int j = l; j < R; j++) size += leader[j] == l;
+        const int g = base[l] + pos[r] / PCL_TRIM_Y, y = pos[r] % PCL_TRIM_Y;
+        PclTrimGroup* gr = groups + g;
+        // the member's yaw relative to the class's first rotation: RZ(delta) = R_member R_leader^T (double)
+        double sd = 0.0, cd = 1.0, t = 0.0;
+        if (l != r) {
+            double A[9], B[9];
+            pcl_trim_rot_d(rot + 3 * r, A);
+            pcl_trim_rot_d(rot + 3 * l, B);
+            const double a00 = A[0] * B[0] + A[1] * B[1] + A[2] * B[2], a10 = A[3] * B[0] + A[4] * B[1] + A[5] * B[2];
+            const double delta = atan2(a10, a00);
+            sincos(delta, &sd, &cd);
+            const double two_pi = 6.283185307179586476925287;
+            t = delta / two_pi;
+            t -= floor(t);
+        }
+        // (what the kernel adds is 0.5 - turns: its column coordinate runs against phi; and it wants -sin, -cos: see there)
+        gr->ns[y] = (float)-sd; gr->nc[y] = (float)-cd; gr->turn[y] = (float)(0.5 - t); gr->rot_idx[y] = r;
+        {
+            float Rm[9];
+            pcl_rot_from_ypr(rot[3 * r], rot[3 * r + 1], rot[3 * r + 2], Rm);       // the matrix the generic kernel multiplies with
+            gr->row1[y][0] = Rm[3]; gr->row1[y][1] = Rm[4]; gr->row1[y][2] = Rm[5];
+        }
+        if (y == 0) {
+            const int left = size - (pos[r] / PCL_TRIM_Y) * PCL_TRIM_Y;
+            gr->ny = left < PCL_TRIM_Y ? left : PCL_TRIM_Y;
+            gr->leader = l;
+            for (int k = gr->ny; k < PCL_TRIM_Y; k++) {
+                gr->ns[k] = 0.f; gr->nc[k] = -1.f; gr->turn[k] = 0.5f; gr->rot_idx[k] = -1;
+                gr->row1[k][0] = 0.f; gr->row1[k][1] = 1.f; gr->row1[k][2] = 0.f;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        hdr->R = R;
+        int total = 0;
+        for (int l = 0; l < R; l++) {
+            if (leader[l] != l) continue;
+            int size = 0;
+            for (int j = l; j < R; j++) size += leader[j] == l;
+            total += (size + PCL_TRIM_Y - 1) / PCL_TRIM_Y;
+        }
+        hdr->ngroups = total;
+    }
+}
+
+extern "C" size_t pcl_trim_groups_bytes(int R) { return R > 0 ? sizeof(PclTrimHeader) + (size_t)R * sizeof(PclTrimGroup) : 0; }
+
+extern "C" int pcl_trim_groups(const float* rot, int R, void* groups, void* stream)
+{
+    if (!rot || !groups || R <= 0 || R > 1024) return PCL_EINVAL;      // (36 R bytes of LDS; the reference's grids have 8 .. 64 rotations)
+    PclTrimHeader* hdr = (PclTrimHeader*)groups;
+    hipLaunchKernelGGL(pcl_trim_groups_kernel, dim3(1), dim3(256), (size_t)R * (3 * sizeof(double) + 3 * sizeof(int)), (hipStream_t)stream, rot, R, hdr,
+                       (PclTrimGroup*)(hdr + 1));
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// pose records of the (group, translation) slots: R = the class's first rotation, t = trans[k]; slot = g * K + k
+__global__ void pcl_trim_pose_setup_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int K, const PclTrimHeader* __restrict__ hdr,
+                                           const PclTrimGroup* __restrict__ groups, int ngroups, PclPoseRec* recs)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= ngroups * K) return;
+    const int g = slot / K, k = slot - g * K;
+    if (g >= hdr->ngroups) return;
+    const int l = groups[g].leader;
+    float p[6] = {trans[3 * k], trans[3 * k + 1], trans[3 * k + 2], rot[3 * l], rot[3 * l + 1], rot[3 * l + 2]};
+    pcl_write_pose_rec(&recs[slot], p);
+}
+
+// ---------------------------------------------------------------- the forward pass
+struct PclTrimArgs {
+    const float* cloud;
+    int64_t n, stride;
+    const void* pano;
+    PclDims dims;
+    const PclPoseRec* poses;         // [ngroups * K]
+    const PclTrimHeader* hdr;
+    const PclTrimGroup* groups;
+    int K, nslots;                   // nslots = ngroups (host's count) * K
+    float* partials;                 // [nchunks][nslots][PCL_TRIM_Y][2]
+    int nchunks, seg_len, steps_base, steps_rem;
+};
+
+#define PCL_STEP (2 * PCL_BLOCK)
+
+// gathers of one point for the panorama row offset `row` (texels) and column x0
+template <int FMT>
+__device__ __forceinline__ void pcl_issue_taps_row(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<FMT>& o);
+template <>
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<PCL_PANO_U8>& o)
+{
+    int voff = (row + x0) * 4;
+    o.top = pcl_texel_pair_u8(tex, voff, 0);
+    o.bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
+}
+template <>
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F16>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<PCL_PANO_F16>& o)
+{
+    int voff = (row + x0) * 8;
+    o.top = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0);
+    o.bot = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0);
+}
+template <>
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F32>(__amdgpu_buffer_rsrc_t, int row, int x0, int Wp, PclTaps<PCL_PANO_F32>& o)
+{
+    o.voff = (row + x0) * 16;
+    o.row = Wp * 16;
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
+{
+    // same XCD-aware mapping as pcl_loss_kernel: blocks b and b + 8 share an XCD; within an XCD the slot varies fastest, so the
+    // blocks resident together read the same cloud chunk; consecutive slots are neighbouring translations of one class
+    const int lq = (int)(blockIdx.x >> 3) / a.nslots, slot = (int)(blockIdx.x >> 3) - lq * a.nslots;
+    const int run = lq / a.seg_len;
+    const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lq - run * a.seg_len);
+    const int g = slot / a.K;
+    const PclTrimGroup* __restrict__ gr = a.groups + g;
+    float* out = a.partials + ((int64_t)chunk * a.nslots + slot) * PCL_NACC;
+    if (g >= a.hdr->ngroups) {                                   // (the host's group count is an upper bound)
+        if (threadIdx.x < PCL_NACC) out[threadIdx.x] = 0.f;
+        return;
+    }
+    const int ny = gr->ny;
+    const PclPoseRec* __restrict__ pose = a.poses + slot;
+
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
+    __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
+    const int plane = (int)a.stride * 4;
+
+    f2 acc[PCL_TRIM_Y][PCL_NACC];          // only [y][0] is used by the forward-only sampler
+    int count[PCL_TRIM_Y];
+#pragma unroll
+    for (int y = 0; y < PCL_TRIM_Y; y++) { count[y] = 0; acc[y][0] = F2(0.f); }
+
+    int first = chunk * a.steps_base + min(chunk, a.steps_rem);
+    int nsteps = a.steps_base + (chunk < a.steps_rem ? 1 : 0);
+    const int begin = first * PCL_STEP;
+    int end = begin + nsteps * PCL_STEP;
+    if (end > (int)a.n) end = (int)a.n;
+    const int last = (int)a.n - 1;
+
+    auto load_step = [&](int base, float (&dst)[2][6]) {
+        int j0 = min(base + (int)threadIdx.x, last), j1 = min(base + PCL_BLOCK + (int)threadIdx.x, last);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            dst[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j0 * 4, k * plane, 0));
+            dst[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(cld, j1 * 4, k * plane, 0));
+        }
+    };
+    const float inv_two_pi = 0.15915494309189533577f;
+    auto eval_step = [&](int base, const float (&src)[2][6]) {
+        const int i0 = base + threadIdx.x, i1 = i0 + PCL_BLOCK;
+        const bool valid0 = i0 < end, valid1 = i1 < end;
+        const unsigned long long vmask0 = __builtin_amdgcn_ballot_w64(valid0), vmask1 = __builtin_amdgcn_ballot_w64(valid1);
+        f2 x = {src[0][0], src[1][0]}, y = {src[0][1], src[1][1]}, z = {src[0][2], src[1][2]};
+        f2 ncr = {src[0][3], src[1][3]}, ncg = {src[0][4], src[1][4]}, ncb = {src[0][5], src[1][5]};
+        // ---- shared by the yaws: q' = RY RX (x - t), rho, the row (theta) and phi0
+        f2 qx, qy, qz;
+        pcl_rotate2(x, y, z, pose, qx, qy, qz);
+        f2 rho2 = pcl_fma2(qx, qx, qy * qy);
+        f2 rg = rho2 + F2(1e-37f);
+        f2 rinv = {__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
+        f2 rho = rho2 * rinv;
+        f2 elev = pcl_elevation2(qz + F2(1e-6f), rho);
+        const float lim_el = 0.495f * 3.14159265358979323846f;
+        f2 elc = {__builtin_amdgcn_fmed3f(elev.x, -lim_el, lim_el), __builtin_amdgcn_fmed3f(elev.y, -lim_el, lim_el)};
+        f2 iy = pcl_fma2(elc, F2(a.dims.k_iy), F2(a.dims.off_y));
+        const int row0 = (int)__umul24((unsigned)(int)iy.x, (unsigned)a.dims.Wp), row1 = (int)__umul24((unsigned)(int)iy.y, (unsigned)a.dims.Wp);
+        const f2 fy = {__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
+        // The column in turns, counted the way the image runs: f = 0.5 - phi / 2 pi in [0, 1] <-> phi in [-pi, pi]; g = f - 0.5.
+        // -phi0 / 2 pi, and the first-order carry of the reference's p_x + 1e-6:  d phi = -eps p_y / rho^2
+        f2 u0 = pcl_atan2_2(qy, qx) * F2(-inv_two_pi);
+        f2 nkk = (rinv * rinv) * F2(-1e-6f * inv_two_pi);
+        // a point within 0.1 mm of the camera's vertical axis: the expansion in eps / rho no longer holds — the wave takes
+        // the exact atan2(p_y, p_x + eps) for its lanes that need it (wave-uniform branch, practically never taken)
+        const bool tiny0 = rho2.x < 1e-8f, tiny1 = rho2.y < 1e-8f;
+        const bool any_tiny = __builtin_amdgcn_ballot_w64(tiny0 || tiny1) != 0ull;
+        // phase A for every yaw of the group: column, fractions, gathers issued — phase B samples them.  (All the group's
+        // gathers are in flight together: with four panorama regions per block the kernel waits on texels, not on VALU issue —
+        // measured VALU busy 0.78 with the phases interleaved per yaw.)
+        PclProj<FMT> pj[PCL_TRIM_Y];
+#pragma unroll
+        for (int yy = 0; yy < PCL_TRIM_Y; yy++) {
+            if (yy >= ny) break;
+            const float ns = gr->ns[yy], nc = gr->nc[yy], turn = gr->turn[yy];
+            f2 npy = pcl_fma2(F2(ns), qx, F2(nc) * qy);                     // -p_y
+            f2 u = pcl_fma2(nkk, npy, u0) + F2(turn);                       // 0.5 - phi / 2 pi, before wrapping into [0, 1)
+            f2 gg = (f2){__builtin_amdgcn_fractf(u.x), __builtin_amdgcn_fractf(u.y)} - F2(0.5f);
+            if (any_tiny) {
+                f2 px = pcl_fma2(F2(-nc), qx, F2(ns) * qy);
+                f2 ge = pcl_atan2_2(-npy, px + F2(1e-6f)) * F2(-inv_two_pi);
+                gg = (f2){tiny0 ? ge.x : gg.x, tiny1 ? ge.y : gg.y};
+            }
+            // Which END of the panorama a point at phi = +-pi belongs to is decided by the sign of p_y, like atan2 decides it
+            // (phi >= 0 <=> p_y >= +0 <=> g <= 0) — and the sum phi0 + yaw has forgotten on which side it started.  Whole planes of
+            // a synthetic room sit exactly there under quarter-turn rotations (camera at floor height: q_z = 0), with a p_y of 1e-8
+            // whose sign only the member's OWN fp32 matrix knows: lanes within 1e-5 turns of the seam take the sign of
+            // p_y = R[1,:] (x - t) evaluated like the generic kernel evaluates it (wave-uniform branch; a handful of waves per
+            // launch on scanned data).
+            const bool seam0 = fabsf(gg.x) > 0.49999f, seam1 = fabsf(gg.y) > 0.49999f;
+            if (__builtin_amdgcn_ballot_w64(seam0 || seam1) != 0ull) {
+                const float r3 = gr->row1[yy][0], r4 = gr->row1[yy][1], r5 = gr->row1[yy][2];
+                f2 wx = x - F2(pose->t[0]), wy = y - F2(pose->t[1]), wz = z - F2(pose->t[2]);
+                f2 pye = pcl_fma2(F2(r5), wz, pcl_fma2(F2(r4), wy, wx * F2(r3)));
+                gg = (f2){seam0 ? copysignf(gg.x, -pye.x) : gg.x, seam1 ? copysignf(gg.y, -pye.y) : gg.y};
+            }
+            // clip to |g_x| <= 0.99 (utils.py:97), pixel coordinate in the bordered texture: ix = W (g + 0.5) - 0.5 + 1
+            f2 gc = {__builtin_amdgcn_fmed3f(gg.x, -0.495f, 0.495f), __builtin_amdgcn_fmed3f(gg.y, -0.495f, 0.495f)};
+            f2 ix = pcl_fma2(gc, F2(2.f * a.dims.half_w), F2(a.dims.half_w + 0.5f));
+            pj[yy].px = pj[yy].py = pj[yy].pz = F2(0.f);                    // (read only by the gradient variant of the sampler)
+            pj[yy].fx = (f2){__builtin_amdgcn_fractf(ix.x), __builtin_amdgcn_fractf(ix.y)};
+            pj[yy].fy = fy;
+            pcl_issue_taps_row<FMT>(tex, row0, (int)ix.x, a.dims.Wp, pj[yy].ta);
+            pcl_issue_taps_row<FMT>(tex, row1, (int)ix.y, a.dims.Wp, pj[yy].tb);
+        }
+#pragma unroll
+        for (int yy = 0; yy < PCL_TRIM_Y; yy++) {
+            if (yy >= ny) break;
+            pcl_sample2<false, FMT>(pj[yy], ncr, ncg, ncb, valid0, valid1, vmask0, vmask1, tex, a.dims, acc[yy], count[yy]);
+        }
+    };
+    float bufA[2][6], bufB[2][6];
+    load_step(begin, bufA);
+    for (int base = begin; base < end; base += 2 * PCL_STEP) {
+        load_step(base + PCL_STEP, bufB);
+        eval_step(base, bufA);
+        if (base + PCL_STEP < end) {
+            load_step(base + 2 * PCL_STEP, bufA);
+            eval_step(base + PCL_STEP, bufB);
+        }
+    }
+
+    __shared__ float red[PCL_BLOCK / PCL_WAVE][PCL_NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int y = 0; y < PCL_TRIM_Y; y++) {
+        float s = pcl_wave_sum(acc[y][0].x + acc[y][0].y);
+        if (lane == 0) { red[wave][2 * y] = s; red[wave][2 * y + 1] = (float)count[y]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < PCL_NACC) out[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// loss_table[k][rot] = sum ||d|| / count over the chunks (fixed order, double): one thread per (slot, yaw)
+__global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __restrict__ partials, int nchunks, int nslots, int K, int R,
+                                                              const PclTrimHeader* __restrict__ hdr, const PclTrimGroup* __restrict__ groups,
+                                                              float* __restrict__ loss_table, float* __restrict__ count_table)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nslots * PCL_TRIM_Y) return;
+    const int slot = id / PCL_TRIM_Y, y = id - slot * PCL_TRIM_Y;
+    const int g = slot / K, k = slot - g * K;
+    if (g >= hdr->ngroups || y >= groups[g].ny) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = 0; c < nchunks; c++) {
+        const float* p = partials + ((int64_t)c * nslots + slot) * PCL_NACC + 2 * y;
+        s0 += (double)p[0]; s1 += (double)p[1];
+    }
+    const int j = groups[g].rot_idx[y];
+    loss_table[(int64_t)k * R + j] = (float)s0 / (float)s1;           // 0 / 0 = NaN like the reference's mean of nothing
+    if (count_table) count_table[(int64_t)k * R + j] = (float)s1;
+}
+
+static size_t trim_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups)
+{
+    if (n <= 0 || K <= 0 || ngroups <= 0) return 0;
+    int nchunks, seg_len, sb, sr;
+    pcl_plan_for_groups(n, ngroups * K, &nchunks, &seg_len, &sb, &sr);
+    return trim_align((size_t)ngroups * K * sizeof(PclPoseRec)) + trim_align((size_t)nchunks * ngroups * K * PCL_NACC * sizeof(float));
+}
+
+extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans, int K,
+                             const float* rot, int R, const void* groups, int ngroups, float* loss_table, float* count_table,
+                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !pano || !trans || !rot || !groups || !loss_table || !workspace) return PCL_EINVAL;
+    if (n <= 0 || n > PCL_MAX_POINTS || K <= 0 || R <= 0 || ngroups <= 0 || ngroups > R || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
+    if ((int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
+    if ((int64_t)ngroups * K > (1 << 24)) return PCL_EINVAL;
+    if (workspace_bytes < pcl_trim_loss_workspace_bytes(n, K, ngroups)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const PclTrimHeader* hdr = (const PclTrimHeader*)groups;
+    const PclTrimGroup* grs = (const PclTrimGroup*)(hdr + 1);
+    const int nslots = ngroups * K;
+    PclPoseRec* recs = (PclPoseRec*)workspace;
+    float* partials = (float*)((char*)workspace + trim_align((size_t)nslots * sizeof(PclPoseRec)));
+    hipLaunchKernelGGL(pcl_trim_pose_setup_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, trans, rot, K, hdr, grs, ngroups, recs);
+    PclTrimArgs a;
+    a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
+    a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
+    a.poses = recs; a.hdr = hdr; a.groups = grs; a.K = K; a.nslots = nslots; a.partials = partials;
+    pcl_plan_for_groups(n, nslots, &a.nchunks, &a.seg_len, &a.steps_base, &a.steps_rem);
+    const int64_t nblk = (int64_t)a.nchunks * nslots;
+    if (nblk > 0x7fffffffll) return PCL_EINVAL;
+    if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    else if (pano_format == PCL_PANO_F16) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F16>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F32>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(pcl_trim_finish_kernel, dim3((nslots * PCL_TRIM_Y + 255) / 256), dim3(256), 0, s, partials, a.nchunks, nslots, K, R,
+                       hdr, grs, loss_table, count_table);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}

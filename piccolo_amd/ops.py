@@ -128,6 +128,38 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
+class TrimGroups:
+    """Classes of equal (pitch, roll) of an (R, 3) rotation table, built on the device (pcl_trim_groups) — what trim_loss_table
+    needs from the rotation grid.  Built once per grid: the group count is read back here (one 4-byte D2H copy), so that the
+    per-image launches are sized exactly."""
+
+    def __init__(self, rot):
+        lib = _lib.load()
+        self.rot = _dev(rot).reshape(-1, 3)
+        self.R = int(self.rot.shape[0])
+        if self.R <= 0:
+            raise ValueError("empty rotation table")
+        self.data = _bytes(lib.pcl_trim_groups_bytes(self.R))
+        _lib.check(lib.pcl_trim_groups(_ptr(self.rot), self.R, _ptr(self.data), _stream()), "pcl_trim_groups")
+        self.ngroups = int(self.data[:4].view(torch.int32).item())
+
+
+def trim_loss_table(cloud, pano, trans, groups, return_count=False):
+    """utils.py:484-499 for all pairs: (K, R) float GPU tensor loss_table[i, j] = forward-only sampling loss of (trans[i], rot[j]),
+    rotations of one (pitch, roll) class sharing the projection (csrc/pcl_trim.hip)."""
+    lib = _lib.load()
+    trans = _dev(trans).reshape(-1, 3)
+    K = int(trans.shape[0])
+    table = torch.empty(K, groups.R, dtype=F32, device=trans.device)
+    count = torch.empty(K, groups.R, dtype=F32, device=trans.device) if return_count else None
+    nws = lib.pcl_trim_loss_workspace_bytes(cloud.n, K, groups.ngroups)
+    ws = _bytes(nws)
+    _lib.check(lib.pcl_trim_loss(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(trans), K, _ptr(groups.rot),
+                                 groups.R, _ptr(groups.data), groups.ngroups, _ptr(table), _ptr(count), _ptr(ws), nws, _stream()),
+               "pcl_trim_loss")
+    return (table, count) if return_count else table
+
+
 def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
     `cloud` is a packed Cloud.  Candidates are processed `batch` at a time (H*W*8 bytes of workspace each: the point lists

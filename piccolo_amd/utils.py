@@ -167,15 +167,15 @@ def make_pano(xyz, rgb, resolution=(200, 400), return_torch=False):
 # ------------------------------------------------------------------------------------------------ initialisation
 def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     """Keep the `num_input` (translation, rotation) pairs with the smallest sampling loss out of all K x R pairs.
-    The reference loops K*R forwards in Python (utils.py:484-499); here all pairs go through one fused launch."""
+    The reference loops K*R forwards in Python (utils.py:484-499); here all pairs go through ONE launch in which the rotations
+    that differ only in yaw share the projection of every point (csrc/pcl_trim.hip): the candidate rotations are a yaw x pitch x
+    roll grid (utils.py:321-360), and for R = RZ(yaw) RY RX neither the panorama row nor the distance depends on yaw."""
+    from .omniloc import _cached
     K, Rn = len(trans), len(rot)
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img, many_poses=True)
-    # rotation-major launch order: pose groups that run together then share the rotation and differ by a grid step of
-    # translation, so they gather neighbouring texels (3 % faster than translation-major); back to the reference's
-    # row-major (K, R) loss_table afterwards
-    tt = ops._dev(trans).repeat(Rn, 1)
-    rr = ops._dev(rot).repeat_interleave(K, dim=0)
-    table = ops.sampling_loss(cloud, pano, tt, rr, with_grad=False)[:, 0].reshape(Rn, K).t().reshape(-1)
+    # the (pitch, roll) classes of the rotation table: once per table (the grid is cached per config in make_input)
+    groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot)) if torch.is_tensor(rot) else ops.TrimGroups(rot)
+    table = ops.trim_loss_table(cloud, pano, trans, groups).reshape(-1)          # row-major (K, R) like the reference's loss_table
     num_input = min(num_input, K * Rn)
     # loss_table.argsort()[:num_input] (utils.py:500-501); topk is one selection kernel where argsort of a few thousand
     # values runs ~100 tiny merge-sort launches (1 ms per image); NaN losses (nothing sampled) rank last in both

@@ -199,6 +199,79 @@ def test_trim_input_loss_golden(ops):
     assert np.array_equal(tt.cpu().numpy(), g["trimmed_trans"]) and np.array_equal(tr.cpu().numpy(), g["trimmed_rot"])
 
 
+def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, parity):
+    """pcl_trim_loss (csrc/pcl_trim.hip: rotations that differ only in yaw share the projection, phi = phi0 + yaw with the
+    first-order carry of the reference's `x + 1e-6`) against (a) the generic forward-only kernel pair by pair and (b) the
+    fp64 oracle, for the reference's grid shapes: the 24-rotation Stanford grid (classes of 1..4 yaws), the yaw-only grid of
+    omniscenes.ini (one class of 8 yaws = two blocks of 4), arbitrary rotations (every class a single yaw, yaws outside
+    [0, 2 pi)), one translation, and all three texel formats.  The G7 table of the reference itself is compared as well."""
+    from piccolo_amd import synth, utils
+    from test_hip_harness import STANFORD
+    n, H, W = 60_000, 128, 256
+    xyz, rgb = synth.box_room(n, 5)
+    xyz[:3] = [[0.3, -0.2, 0.9], [0.3, -0.2, -1.1], [0.3 + 2e-5, -0.2, 1.0]]        # on / next to a camera's vertical axis (trans[0])
+    X, C = T(xyz), T(rgb)
+    t_gt, ypr_gt = synth.gt_pose(5)
+    img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, T(t_gt), T(ypr_gt)), C, (H, W)))
+    img_host = img.cpu().numpy()
+    cloud = ops.Cloud(X, C)
+    rng = np.random.default_rng(3)
+    trans = np.concatenate([[[0.3, -0.2, 0.1]], rng.uniform(-1.5, 1.5, size=(6, 3))]).astype(np.float32)
+    stanford = utils.generate_rot_points(dict(STANFORD), device=X.device).cpu().numpy()
+    assert stanford.shape == (24, 3)
+    yaw_only = np.zeros((8, 3), np.float32)
+    yaw_only[:, 0] = np.arange(8) * 2 * np.pi / 8
+    loose = rng.uniform(-7.0, 7.0, size=(5, 3)).astype(np.float32)
+    mixed = np.concatenate([loose, loose[:2] + np.float32([1.0, 0, 0]), stanford[:7]]).astype(np.float32)
+    cases = [("stanford 24", stanford, trans, "u8"), ("yaw only 8", yaw_only, trans, "u8"), ("arbitrary + repeats", mixed, trans, "u8"),
+             ("one translation", stanford, trans[:1], "u8"), ("fp16-level texels", stanford, trans[:3], "f16"),
+             ("float4 texels", yaw_only, trans[:3], "f32")]
+    for name, rot, tr, fmt in cases:
+        pano = ops.Pano(img, fmt=fmt)
+        groups = ops.TrimGroups(T(rot))
+        table, count = ops.trim_loss_table(cloud, pano, T(tr), groups, return_count=True)
+        table, count = table.cpu().numpy(), count.cpu().numpy()
+        K, R = len(tr), len(rot)
+        assert table.shape == (K, R)
+        # classes: rotations with the same third row (they differ by a yaw), four yaws per group
+        zrows = [synth.rot_from_ypr_np(r.astype(np.float64))[2] for r in rot]
+        leaders, sizes = [], []
+        for z in zrows:
+            for i, l in enumerate(leaders):
+                if np.abs(z - l).max() <= 4e-7:
+                    sizes[i] += 1
+                    break
+            else:
+                leaders.append(z)
+                sizes.append(1)
+        assert groups.ngroups == sum((v + 3) // 4 for v in sizes), (name, groups.ngroups, sizes)
+        if name == "stanford 24":
+            assert sizes == [4] * 6                      # the 24 quarter-turn rotations: 6 classes of 4 yaws
+        tt, rr = np.repeat(tr, R, 0), np.tile(rot, (K, 1))                    # row-major (K, R)
+        gen = ops.sampling_loss(cloud, pano, T(tt), T(rr), with_grad=False).cpu().numpy()
+        ref = oracle.sampling_loss(xyz, rgb, img_host, tt, rr, dtype=np.float64, grad=False)
+        dcount = float(np.abs(count.reshape(-1) - ref["count"]).max())
+        parity(name + ": mask count vs fp64 oracle (points)", dcount, 4)
+        # A point within 2e-6 rad of phi = +-pi lands on either END of the panorama depending on the last bit of any fp32
+        # evaluation (the axis points above sit exactly there under the grid's quarter-turn rotations): like a mask flip, such a
+        # point moves the mean by up to ~2/n.  Counted in fp64 per pair.
+        Rm = np.stack([synth.rot_from_ypr_np(r.astype(np.float64)) for r in rr])
+        p = np.einsum("bij,bnj->bni", Rm, xyz[None].astype(np.float64) - tt[:, None].astype(np.float64))
+        nseam = int((np.pi - np.abs(np.arctan2(p[..., 1], p[..., 0] + 1e-6)) < 2e-6).sum(1).max())
+        flips = max(dcount, float(np.abs(count.reshape(-1) - gen[:, 1]).max())) + nseam
+        parity(name + ": loss table vs the generic forward kernel", rel(table.reshape(-1), gen[:, 0]), 3e-7 + 2.0 * flips / n)
+        parity(name + ": loss table vs fp64 oracle", rel(table.reshape(-1), ref["loss"]), 3e-7 + 2.0 * flips / n, rel(gen[:, 0], ref["loss"]))
+    # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once
+    groups = ops.TrimGroups(T(stanford))
+    want = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()
+    groups.ngroups = 24
+    assert np.array_equal(ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy(), want)
+    # G7: the reference's own loss table
+    g = load_golden("g7_trim_input_loss.npz")
+    tab = ops.trim_loss_table(ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]), fmt="u8"), T(g["trans"]), ops.TrimGroups(T(g["rot"]))).cpu().numpy()
+    parity("G7: loss table vs the reference's (fp32 torch)", rel(tab, g["loss_table"].reshape(tab.shape)), 2e-6)
+
+
 # --------------------------------------------------------------------------------------- GD loops
 def _gd_hist(ops, g, mode_batch, trans, rot, n_it, cfg):
     cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
