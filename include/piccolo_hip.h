@@ -39,7 +39,7 @@ extern "C" {
 int pcl_abi_version(void);
 const char *pcl_error_string(int code);
 /* Which sources the loss kernel of THIS binary was compiled from: the first 16 hex digits of sha256(csrc/pcl_loss.hip +
- * csrc/pcl_sample_device.h + csrc/pcl_device.h), stamped in by piccolo_amd/build.py ("unstamped" for a build that did not pass -DPCL_SOURCE_HASH).
+ * csrc/pcl_sample_device.h + csrc/pcl_gd_device.h + csrc/pcl_device.h), stamped in by piccolo_amd/build.py ("unstamped" for a build that did not pass -DPCL_SOURCE_HASH).
  * Measurement aid: counter-derived figures (VALU instructions per point-pose, profiles/roofs.json) carry the hash of the
  * library they were collected from, and bench.py reports them only for a library with the same hash. */
 const char *pcl_source_hash(void);

@@ -27,11 +27,11 @@ def sources():
 
 
 def loss_kernel_source_hash():
-    """First 16 hex digits of sha256(csrc/pcl_loss.hip + csrc/pcl_sample_device.h + csrc/pcl_device.h): what pcl_source_hash() of a library built from this
+    """First 16 hex digits of sha256(csrc/pcl_loss.hip + csrc/pcl_sample_device.h + csrc/pcl_gd_device.h + csrc/pcl_device.h): what pcl_source_hash() of a library built from this
     tree returns.  Counter-derived figures in profiles/roofs.json carry it; bench.py reports them only when it matches."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("pcl_loss.hip", "pcl_sample_device.h", "pcl_device.h"):
+    for name in ("pcl_loss.hip", "pcl_sample_device.h", "pcl_gd_device.h", "pcl_device.h"):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

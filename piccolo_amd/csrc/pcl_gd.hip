@@ -10,9 +10,11 @@
 #include "pcl_gd_device.h"
 
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip);
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse);
 size_t pcl_partials_bytes(int64_t n, int B);
 int pcl_plan_nchunks(int64_t n, int B);
+int pcl_plan_nblocks(int64_t n, int B);
+int pcl_plan_G(int64_t n, int B);
 size_t pcl_depth_zbuf_bytes(int B, int H, int W);
 int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
                           uint32_t* zbuf, uint8_t* visible, hipStream_t s);
@@ -27,20 +29,20 @@ __global__ void pcl_pose_setup_kernel(const float* __restrict__ trans, const flo
     pcl_write_pose_rec(&recs[b], p);
 }
 
+// one block per pose group: second-stage sums (the same fixed order as the GD epilogue), then thread g finishes pose g
+template <int G>
 __global__ void __launch_bounds__(PCL_GD_THREADS) pcl_finish_kernel(const float* __restrict__ partials, int nchunks, int B,
                                                                     const PclPoseRec* __restrict__ recs,
                                                                     const float* __restrict__ rot, int with_grad,
                                                                     float* __restrict__ result)
 {
-    int b = blockIdx.x;
-    __shared__ double red[PCL_GD_THREADS / PCL_WAVE][PCL_NACC];
-    double s[PCL_NACC];
-    pcl_reduce_partials(partials, nchunks, B, b, threadIdx.x, PCL_GD_THREADS, s);
-    if ((threadIdx.x & 63) == 0)
-        for (int q = 0; q < PCL_NACC; q++) red[threadIdx.x >> 6][q] = s[q];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int q = 0; q < PCL_NACC; q++) s[q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+    __shared__ double rows_sh[(PCL_GD_THREADS / 16) * 2 * G][4];
+    __shared__ double sums_sh[G][PCL_NACC];
+    pcl_reduce_group<G>(partials, nchunks, blockIdx.x, threadIdx.x, rows_sh, sums_sh);
+    if (threadIdx.x < G) {
+        const int b = blockIdx.x * G + threadIdx.x;
+        double s[PCL_NACC];
+        for (int q = 0; q < PCL_NACC; q++) s[q] = sums_sh[threadIdx.x][q];
         float loss, g[6] = {0, 0, 0, 0, 0, 0};
         if (with_grad) {
             double sy, cy, sp, cp;
@@ -72,21 +74,29 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano
     float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
     hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
     PCL_LAUNCH_CHECK();
-    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s, 0);
+    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s, 0, nullptr);
     if (rc) return rc;
-    hipLaunchKernelGGL(pcl_finish_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, pcl_plan_nchunks(n, B), B, recs, rot,
-                       with_grad, result);
+    const int G = pcl_plan_G(n, B), nch = pcl_plan_nchunks(n, B);
+    if (G == 4) hipLaunchKernelGGL(pcl_finish_kernel<4>, dim3(B / 4), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
+    else if (G == 2) hipLaunchKernelGGL(pcl_finish_kernel<2>, dim3(B / 2), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
+    else hipLaunchKernelGGL(pcl_finish_kernel<1>, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
     PCL_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------- GD: state init, epilogue, run, result
 
-// state blob = PclGdPose[B] followed by PclPoseRec[B]
-static inline PclGdPose* gd_poses(void* state) { return (PclGdPose*)state; }
-static inline PclPoseRec* gd_recs(void* state, int B) { return (PclPoseRec*)((char*)state + (size_t)B * sizeof(PclGdPose)); }
+// state blob = { PclGdPose[B], PclPoseRec[B] } x 2: copy 0 is the canonical one (what pcl_gd_init fills and pcl_gd_result reads);
+// fused iterations ping-pong between the two (a block of iteration k + 1 reads iteration k's copy while the block of chunk 0
+// writes iteration k + 1's).  The panorama addresses of the pose records are kept in both copies.
+static inline size_t gd_copy_bytes(int B) { return (size_t)B * (sizeof(PclGdPose) + sizeof(PclPoseRec)); }
+static inline PclGdPose* gd_poses(void* state, int B = 0, int copy = 0) { return (PclGdPose*)((char*)state + (size_t)copy * gd_copy_bytes(B)); }
+static inline PclPoseRec* gd_recs(void* state, int B, int copy = 0)
+{
+    return (PclPoseRec*)((char*)state + (size_t)copy * gd_copy_bytes(B) + (size_t)B * sizeof(PclGdPose));
+}
 
-__global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float* __restrict__ trans,
+__global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, PclPoseRec* recs_shadow, const float* __restrict__ trans,
                                    const float* __restrict__ rot, int B, double lr)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,15 +110,21 @@ __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, const float*
     g.beta1_pow = 1.0; g.beta2_pow = 1.0;
     recs[b].pano_lo = 0u; recs[b].pano_hi = 0u; recs[b].pad[0] = recs[b].pad[1] = 0.f;
     pcl_write_pose_rec_fast(&recs[b], g.fwd, g.sc);
+    recs_shadow[b] = recs[b];
     st[b] = g;
 }
 
-__global__ void __launch_bounds__(PCL_GD_THREADS) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks, int B,
-                                                                         PclGdPose* st, PclPoseRec* recs,
+template <int G>
+__global__ void __launch_bounds__(PCL_GD_THREADS) pcl_gd_epilogue_kernel(const float* __restrict__ partials, int nchunks,
+                                                                         const PclGdPose* st_in, const PclPoseRec* recs_in,
+                                                                         PclGdPose* st_out, PclPoseRec* recs_out,
                                                                          const float* __restrict__ box, double factor,
                                                                          int patience, int mode, float* loss_out)
 {
-    pcl_gd_finish_pose(partials, nchunks, B, blockIdx.x, threadIdx.x, st, recs, box, factor, patience, mode, loss_out);
+    __shared__ double rows_sh[(PCL_GD_THREADS / 16) * 2 * G][4];
+    __shared__ double sums_sh[G][PCL_NACC];
+    pcl_gd_finish_group<G, false>(partials, nchunks, blockIdx.x, threadIdx.x, st_in, recs_in, st_out, recs_out, true, box, factor, patience, mode,
+                                  loss_out, rows_sh, sums_sh, nullptr);
 }
 
 __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, float* __restrict__ result)
@@ -121,14 +137,14 @@ __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, fl
     r[13] = (float)st[b].lr;
 }
 
-extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? (size_t)B * (sizeof(PclGdPose) + sizeof(PclPoseRec)) : 0; }
+extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? 2 * gd_copy_bytes(B) : 0; }
 
 static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 extern "C" size_t pcl_gd_workspace_bytes(int64_t n, int B, int H, int W, const pcl_gd_hyper* hyper_host)
 {
     if (n <= 0 || B <= 0 || !hyper_host) return 0;
-    size_t bytes = gd_align(pcl_partials_bytes(n, B));
+    size_t bytes = 2 * gd_align(pcl_partials_bytes(n, B));         // (two: fused iterations read one while they write the other)
     if (hyper_host->depth_mask) bytes += gd_align(pcl_depth_zbuf_bytes(B, H, W)) + gd_align((size_t)B * (size_t)n);
     return bytes;
 }
@@ -137,7 +153,7 @@ extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, in
 {
     if (!state || !trans || !rot || !hyper_host || B <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_poses(state),
-                       gd_recs(state, B), trans, rot, B, hyper_host->lr);
+                       gd_recs(state, B), gd_recs(state, B, 1), trans, rot, B, hyper_host->lr);
     PCL_LAUNCH_CHECK();
     return 0;
 }
@@ -237,12 +253,12 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
     if (workspace_bytes < pcl_gd_workspace_bytes(n, B, H, W, hyper_host)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    float* partials = (float*)workspace;
+    float* partials2[2] = {(float*)workspace, (float*)((char*)workspace + gd_align(pcl_partials_bytes(n, B)))};
     uint32_t* zbuf = nullptr;
     uint8_t* visible = nullptr;
     if (hyper_host->depth_mask) {
         if (!(hyper_host->depth_tau >= 0.f) || B > 65535) return PCL_EINVAL;
-        zbuf = (uint32_t*)((char*)workspace + gd_align(pcl_partials_bytes(n, B)));
+        zbuf = (uint32_t*)((char*)workspace + 2 * gd_align(pcl_partials_bytes(n, B)));
         visible = (uint8_t*)zbuf + gd_align(pcl_depth_zbuf_bytes(B, H, W));
     }
     const int nchunks = pcl_plan_nchunks(n, B);
@@ -250,6 +266,28 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     // finished with, still in that XCD's L2 (PCL_FLIP=0 turns it off; +0.3 % at cfg 2 in two A/B alternations on one box —
     // the first round of a launch stays 6 us slower than the later ones, so cold L2 is not what makes it slow)
     static const int flip_env = getenv("PCL_FLIP") ? atoi(getenv("PCL_FLIP")) : 1;
+    // ONE launch per iteration for launches whose blocks are all resident at once (the reference's shipped 167k-point /
+    // 6-candidate shape, cfg 1): there an iteration is two dependent launches of a few microseconds, and the 5 us the epilogue
+    // launch costs are pure dispatch.  The loss launch of iteration k + 1 finishes iteration k in the prologue of every block
+    // (PclFuseArgs) — no inter-block synchronisation, the kernel boundary is the only one; the last iteration is finished by
+    // the stand-alone epilogue.  Same arithmetic in the same order: results are bit-identical to the two-launch form
+    // (PCL_GD_FUSE_BLOCKS: largest grid that takes this path, 0 = never).
+    const char* fuse_env = getenv("PCL_GD_FUSE_BLOCKS");          // (read per call: tests run both forms in one process)
+    const int fuse_blocks = fuse_env && *fuse_env ? atoi(fuse_env) : 1024;
+    const bool fused = !visible && pcl_plan_nblocks(n, B) <= fuse_blocks;
+    const int G = pcl_plan_G(n, B);
+    auto epilogue = [&](int it, int copy_in, float* partials) {
+        const PclGdPose* si = gd_poses(state, B, copy_in);
+        const PclPoseRec* ri = gd_recs(state, B, copy_in);
+        PclGdPose* so = gd_poses(state, B, 0);
+        PclPoseRec* ro = gd_recs(state, B, 0);
+        float* lo = loss_history ? loss_history + (int64_t)it * B : nullptr;
+        const double fac = hyper_host->factor;
+        const int pat = (int)hyper_host->patience, mode = (int)hyper_host->mode;
+        if (G == 4) hipLaunchKernelGGL(pcl_gd_epilogue_kernel<4>, dim3(B / 4), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, si, ri, so, ro, box, fac, pat, mode, lo);
+        else if (G == 2) hipLaunchKernelGGL(pcl_gd_epilogue_kernel<2>, dim3(B / 2), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, si, ri, so, ro, box, fac, pat, mode, lo);
+        else hipLaunchKernelGGL(pcl_gd_epilogue_kernel<1>, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, si, ri, so, ro, box, fac, pat, mode, lo);
+    };
     for (int it = 0; it < num_iter; it++) {
         if (visible) {
             int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, s);
@@ -262,7 +300,20 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             hipError_t e = hipEventRecord(tm->start[tm->used], s);
             if (e != hipSuccess) return (int)e;
         }
-        int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials, s, flip_env ? (it & 1) : 0);
+        int rc;
+        if (fused && it > 0) {
+            // iteration `it` reads copy (it - 1) & 1 of state / pose records / partials and writes copy it & 1
+            const int cin = (it - 1) & 1, cout = it & 1;
+            PclFuseArgs f;
+            f.partials_in = partials2[cin]; f.st_in = gd_poses(state, B, cin); f.recs_in = gd_recs(state, B, cin);
+            f.st_out = gd_poses(state, B, cout); f.recs_out = gd_recs(state, B, cout);
+            f.box = box; f.factor = hyper_host->factor; f.patience = (int)hyper_host->patience; f.mode = (int)hyper_host->mode;
+            f.loss_out = loss_history ? loss_history + (int64_t)(it - 1) * B : nullptr;
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, f.recs_in, B, true, nullptr, partials2[cout], s, flip_env ? (it & 1) : 0, &f);
+        } else {
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials2[0], s, flip_env ? (it & 1) : 0,
+                                 nullptr);
+        }
         if (rc) return rc;
         if (timed) {
             // (only a completed start/stop pair counts as used: pcl_timer_read never sees a half-recorded slot)
@@ -270,28 +321,33 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             if (e != hipSuccess) return (int)e;
             tm->used++;
         }
-        hipLaunchKernelGGL(pcl_gd_epilogue_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, B, gd_poses(state),
-                           gd_recs(state, B), box, hyper_host->factor, (int)hyper_host->patience, (int)hyper_host->mode,
-                           loss_history ? loss_history + (int64_t)it * B : nullptr);
+        if (!fused) {
+            epilogue(it, 0, partials2[0]);
+            PCL_LAUNCH_CHECK();
+        }
+    }
+    if (fused && num_iter > 0) {
+        const int last = (num_iter - 1) & 1;                     // the copy the last launch wrote (copy 0 when it was the only one)
+        epilogue(num_iter - 1, num_iter > 1 ? last : 0, partials2[num_iter > 1 ? last : 0]);
         PCL_LAUNCH_CHECK();
     }
     return 0;
 }
 
-__global__ void pcl_gd_set_panos_kernel(PclPoseRec* recs, const unsigned long long* __restrict__ panos, int B)
+__global__ void pcl_gd_set_panos_kernel(PclPoseRec* recs, PclPoseRec* recs_shadow, const unsigned long long* __restrict__ panos, int B)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     unsigned long long p = panos ? panos[b] : 0ull;
-    recs[b].pano_lo = (uint32_t)(p & 0xffffffffull);
-    recs[b].pano_hi = (uint32_t)(p >> 32);
+    recs[b].pano_lo = recs_shadow[b].pano_lo = (uint32_t)(p & 0xffffffffull);
+    recs[b].pano_hi = recs_shadow[b].pano_hi = (uint32_t)(p >> 32);
 }
 
 extern "C" int pcl_gd_set_panos(void* state, const uint64_t* panos, int B, void* stream)
 {
     if (!state || B <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_set_panos_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_recs(state, B),
-                       (const unsigned long long*)panos, B);
+                       gd_recs(state, B, 1), (const unsigned long long*)panos, B);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -21,6 +21,7 @@
 // plain store of the partials (no atomics: the second-stage reduce in pcl_gd.hip is deterministic).
 #include <stdlib.h>
 
+#include "pcl_gd_device.h"
 #include "pcl_sample_device.h"
 
 struct PclLossArgs {
@@ -31,7 +32,7 @@ struct PclLossArgs {
     const PclPoseRec* poses; // [B]
     int B;
     const uint8_t* visible;  // nullable [B][n]
-    float* partials;         // [nchunks][B][8]
+    float* partials;         // [ngroups][nchunks][G][8] (pcl_partials_row)
     int nchunks;             // multiple of 8
     int ngroups;             // B / G
     int flip;                    // 1: every XCD walks its chunks from the last to the first (see pcl_launch_loss)
@@ -62,8 +63,10 @@ extern "C" int pcl_debug_stamp(unsigned long long* slot, void* stream)
 
 // G poses per block, GRAD: with gradient, VIS: byte visibility mask, FMT: texel format.
 // (Forcing more resident blocks per CU through __launch_bounds__ was tried: the register allocator spills, 2-4x slower.)
-template <int G, bool GRAD, bool VIS, int FMT>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
+// FUSED: the block first finishes the PREVIOUS GD iteration for its own poses (PclFuseArgs, pcl_gd_device.h) and evaluates the
+// poses that come out of it; the block of chunk 0 also stores the optimiser state.  No block waits for another one.
+template <int G, bool GRAD, bool VIS, int FMT, bool FUSED>
+__device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFuseArgs& f)
 {
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.  Within an
     // XCD the pose group varies fastest, so the blocks that are resident together read the same cloud chunk (it stays in
@@ -81,6 +84,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
     const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lc - run * a.seg_len);
     const int pose0 = group * G;
 
+    // the poses this block evaluates, as SGPR pairs: straight from the pose records, or (FUSED) out of the optimiser update below
+    PclPose6 P6[G];
     __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     // the cloud through a buffer resource too: 32-bit lane offsets + scalar plane offsets, no 64-bit address math
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
@@ -152,12 +157,30 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
-            pcl_project2<FMT>(x, y, z, pr, tg, a.dims, pj);
+            if constexpr (FUSED) pcl_project2<FMT>(x, y, z, P6[g], tg, a.dims, pj);
+            else pcl_project2<FMT>(x, y, z, pcl_pose6(pr), tg, a.dims, pj);
             pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tg, a.dims, acc[g], count[g]);
         }
     };
     float bufA[2][6], bufB[2][6];
-    load_step(begin, bufA);
+    load_step(begin, bufA);                            // (in flight while a fused block finishes the previous iteration)
+    if constexpr (FUSED) {
+        static_assert(PCL_BLOCK == PCL_GD_THREADS, "the fused prologue reduces with the epilogue kernel's thread layout");
+        __shared__ double gd_rows[(PCL_GD_THREADS / 16) * 2 * G][4];
+        __shared__ double gd_sums[G][PCL_NACC];
+        __shared__ float pose_sh[G][12];
+        pcl_gd_finish_group<G, true>(f.partials_in, a.nchunks, group, (int)threadIdx.x, f.st_in, f.recs_in, f.st_out, f.recs_out, chunk == 0,
+                                     f.box, f.factor, f.patience, f.mode, f.loss_out, gd_rows, gd_sums, pose_sh);
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            float v[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_sh[g][k])));
+            P6[g] = PclPose6{(f2){v[0], v[1]}, (f2){v[2], v[3]}, (f2){v[4], v[5]}, (f2){v[6], v[7]}, (f2){v[8], v[9]}, (f2){v[10], v[11]}};
+        }
+    }
+
     for (int base = begin; base < end; base += 2 * PCL_STEP) {
         load_step(base + PCL_STEP, bufB);              // clamped to the last point if past the end (evaluated as invalid)
         eval_step(base, bufA);
@@ -187,7 +210,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
         int g = threadIdx.x / PCL_NACC, k = threadIdx.x - g * PCL_NACC;
         float s = 0.f;
         if (GRAD || k < 2) s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        a.partials[((int64_t)chunk * a.B + pose0 + g) * PCL_NACC + k] = s;
+        a.partials[pcl_partials_row(a.nchunks, G, group, chunk, g) + k] = s;          // (one contiguous 32 G-byte row per block)
     }
 #ifdef PCL_BLOCK_TRACE
     if (pcl_trace_buf && threadIdx.x == 0) {
@@ -198,6 +221,18 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
         t[0] = 0; t[1] = 0; t[2] = PCL_TRACE_NOW(); t[3] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
+}
+
+template <int G, bool GRAD, bool VIS, int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
+{
+    pcl_loss_body<G, GRAD, VIS, FMT, false>(a, PclFuseArgs{});
+}
+
+template <int G, int FMT>
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_fused_kernel(PclLossArgs a, PclFuseArgs f)
+{
+    pcl_loss_body<G, true, false, FMT, true>(a, f);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -264,6 +299,8 @@ size_t pcl_partials_bytes(int64_t n, int B)
 }
 
 int pcl_plan_nchunks(int64_t n, int B) { return pcl_plan(n, B).nchunks; }
+int pcl_plan_nblocks(int64_t n, int B) { PclPlan p = pcl_plan(n, B); return p.nchunks * p.ngroups; }
+int pcl_plan_G(int64_t n, int B) { return pcl_plan(n, B).G; }
 
 // the same decomposition for a kernel with its own notion of a pose group (pcl_trim.hip: one block = one chunk x one
 // (translation, rotation class) slot): chunks, XCD runs and balanced steps as for `ngroups` groups of two poses
@@ -304,8 +341,17 @@ static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, bool 
 }
 
 // Enqueue one fused loss(+grad) pass over the cloud for B poses; partials must hold pcl_partials_bytes(n, B).
+template <int FMT>
+static void pcl_launch_fused(const PclLossArgs& a, const PclFuseArgs& f, int G, int nblk, hipStream_t s)
+{
+    if (G == 4) hipLaunchKernelGGL((pcl_loss_fused_kernel<4, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a, f);
+    else if (G == 2) hipLaunchKernelGGL((pcl_loss_fused_kernel<2, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a, f);
+    else hipLaunchKernelGGL((pcl_loss_fused_kernel<1, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a, f);
+}
+
+// `fuse` (nullable): finish the previous GD iteration in the prologue of every block (gradient pass without visibility only)
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip)
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse)
 {
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
@@ -318,6 +364,14 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.flip = flip; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
+    if (fuse) {
+        if (!grad || vis) return PCL_EINVAL;
+        if (pano_format == PCL_PANO_U8) pcl_launch_fused<PCL_PANO_U8>(a, *fuse, p.G, nblk, s);
+        else if (pano_format == PCL_PANO_F16) pcl_launch_fused<PCL_PANO_F16>(a, *fuse, p.G, nblk, s);
+        else pcl_launch_fused<PCL_PANO_F32>(a, *fuse, p.G, nblk, s);
+        PCL_LAUNCH_CHECK();
+        return 0;
+    }
     if (pano_format == PCL_PANO_U8) pcl_launch_f<PCL_PANO_U8>(a, p.G, nblk, grad, vis, s);
     else if (pano_format == PCL_PANO_F16) pcl_launch_f<PCL_PANO_F16>(a, p.G, nblk, grad, vis, s);
     else pcl_launch_f<PCL_PANO_F32>(a, p.G, nblk, grad, vis, s);

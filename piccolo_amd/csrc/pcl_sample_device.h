@@ -173,10 +173,15 @@ struct PclProj {
 // the three rows are interleaved, so every result is used three slots later; same operations in the same order.
 // (The pairs rely on PclPoseRec's layout — t directly behind R[9], static_assert in pcl_device.h — and on the pose
 // pointer being wave-uniform: the "s" constraints below.)
-__device__ __forceinline__ void pcl_rotate2(f2 x, f2 y, f2 z, const PclPoseRec* __restrict__ pose, f2& opx, f2& opy, f2& opz)
+struct PclPose6 { f2 p0, p1, p2, p3, p4, p5; };       // the six SGPR pairs of a pose: (R0,R1)(R2,R3)(R4,R5)(R6,R7)(R8,t0)(t1,t2)
+__device__ __forceinline__ PclPose6 pcl_pose6(const PclPoseRec* __restrict__ pose)
 {
     const f2* __restrict__ P = reinterpret_cast<const f2*>(pose->R);
-    const f2 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3], p4 = P[4], p5 = P[5];
+    return PclPose6{P[0], P[1], P[2], P[3], P[4], P[5]};
+}
+__device__ __forceinline__ void pcl_rotate2(f2 x, f2 y, f2 z, const PclPose6& P, f2& opx, f2& opy, f2& opz)
+{
+    const f2 p0 = P.p0, p1 = P.p1, p2 = P.p2, p3 = P.p3, p4 = P.p4, p5 = P.p5;
     f2 qx, qy, qz, px, py, pz;
     asm("v_pk_add_f32 %3, %6, %13 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"     // qx = x - t0   (hi of p4)
         "v_pk_add_f32 %4, %7, %14 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"                  // qy = y - t1   (lo of p5)
@@ -195,10 +200,14 @@ __device__ __forceinline__ void pcl_rotate2(f2 x, f2 y, f2 z, const PclPoseRec* 
         : "v"(x), "v"(y), "v"(z), "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5));
     opx = px; opy = py; opz = pz;
 }
+__device__ __forceinline__ void pcl_rotate2(f2 x, f2 y, f2 z, const PclPoseRec* __restrict__ pose, f2& opx, f2& opy, f2& opz)
+{
+    pcl_rotate2(x, y, z, pcl_pose6(pose), opx, opy, opz);
+}
 
 // Phase A: q = x - t, p = R q, cloud2idx, clip, pixel + fractions, issue the gathers.
 template <int FMT>
-__device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPoseRec* __restrict__ pose,
+__device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPose6& pose,
                                              __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
 {
     pcl_rotate2(x, y, z, pose, o.px, o.py, o.pz);

@@ -307,6 +307,65 @@ def test_small_utils_match_reference():
     assert np.abs(got - g["bound_q10"]).max() <= 1e-6
 
 
+def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
+    """Launches whose blocks are all resident at once (the reference's shipped 167k-point / 6-candidate shape, cfg 1) run ONE
+    launch per GD iteration: every block of iteration k + 1 finishes iteration k for its own poses in its prologue (same
+    reduction order, chain rule, Adam, scheduler, clamp as the stand-alone epilogue kernel; the block of chunk 0 stores the
+    state), the last iteration is finished by the stand-alone epilogue.  PCL_GD_FUSE_BLOCKS=0 selects the two-launch form:
+    optimiser state, poses, per-iteration loss history and the caller-visible results must agree BIT FOR BIT — both modes,
+    even and odd candidate counts, one candidate, per-candidate panoramas, 1 / 2 / 3 / 100 iterations, run() called in pieces."""
+    import os
+    from piccolo_amd import ops, synth
+    H, W = 64, 128
+    cases = [(20_000, 6, True), (20_000, 5, True), (20_000, 1, False), (20_000, 4, False), (166_667, 6, True), (100_000, 1, False)]
+    old = os.environ.get("PCL_GD_FUSE_BLOCKS")
+    try:
+        for n, B, batch_mode in cases:
+            xyz, rgb = synth.box_room(n, 90 + B)
+            X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+            cloud = ops.Cloud(X, C)
+            box = ops.quantile_box(X, 0.05)
+            panos, tr_all, ro_all = [], [], []
+            for k in range(2):
+                t_gt, ypr_gt = synth.gt_pose(90 + k)
+                img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+                panos.append(ops.Pano(torch.from_numpy(img).cuda()))
+                tr, ro = synth.start_poses(t_gt, ypr_gt, B, seed=90 + k)
+                tr[0, 0] = 4.4                                   # one start outside the clamp box (batch mode's clamp lag)
+                tr_all.append(tr)
+                ro_all.append(ro)
+            tr, ro = torch.from_numpy(tr_all[0]).cuda(), torch.from_numpy(ro_all[0]).cuda()
+            table = [panos[b % 2] for b in range(B)]             # candidates alternate between two panoramas
+            out = {}
+            for mode in ("two", "fused"):
+                os.environ["PCL_GD_FUSE_BLOCKS"] = "0" if mode == "two" else "1024"
+                runs = []
+                for num_iter in (1, 2, 3, 100):
+                    gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                    gd.set_panos(table)
+                    hist = gd.run(num_iter, history=True)
+                    runs.append((hist.clone(), gd.result().clone(), gd.state.clone()[: gd.state.numel() // 2]))
+                # in pieces: 2 + 1 + 4 iterations continue one another exactly like 7 in one call
+                gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                gd.set_panos(table)
+                pieces = torch.cat([gd.run(2, history=True), gd.run(1, history=True), gd.run(4, history=True)])
+                gd7 = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                gd7.set_panos(table)
+                whole = gd7.run(7, history=True)
+                assert torch.equal(pieces, whole) and torch.equal(gd.result(), gd7.result()), (n, B, mode)
+                runs.append((pieces.clone(), gd.result().clone(), gd.state.clone()[: gd.state.numel() // 2]))
+                out[mode] = runs
+            for (h2, r2, s2), (hf, rf, sf) in zip(out["two"], out["fused"]):
+                assert torch.equal(h2, hf), (n, B, "loss history", (h2 - hf).abs().max())
+                assert torch.equal(r2, rf), (n, B, "result")
+                assert torch.equal(s2, sf), (n, B, "optimiser state")          # (canonical copy of the state blob, byte for byte)
+    finally:
+        if old is None:
+            os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
+        else:
+            os.environ["PCL_GD_FUSE_BLOCKS"] = old
+
+
 def test_small_problems_replay_a_cached_graph_and_stay_bit_identical(oracle):
     """Small refinements (points x candidates <= GRAPH_POINT_POSES) go through a GradientDescent object cached per cloud and
     launch shape whose launch chain is captured into a hipGraph once and replayed for every later image.  Results must be
