@@ -160,6 +160,7 @@ template <int FMT>
 struct PclProj {
     f2 px, py, pz;        // camera-frame point
     f2 rho2, rinv;        // px^2 + py^2 and 1/rho
+    f2 rs2;               // 1 / sqrt(rho^2 + (pz + eps)^2): the elevation's half-angle form and the gradient's 1 / s2 share it
     f2 fx, fy;            // bilinear fractions
     bool in_phi0, in_phi1, in_th0, in_th1;   // the +-0.99 clip is inactive (clamp backward passes the gradient only there)
     PclTaps<FMT> ta, tb;  // gathers in flight (point .x, point .y)
@@ -220,15 +221,24 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPose6& p
     o.rinv = (f2){__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
     f2 rho = o.rho2 * o.rinv;
     f2 phi = pcl_atan2_2(o.py, a);
-    f2 elev = pcl_elevation2(b, rho);                       // theta = atan2(rho, b) = pi/2 - elev
+    // Elevation e = atan2(b, rho) (theta = pi/2 - e) by the half-angle form  e = 2 atan(b / (r + rho)),  r = sqrt(rho^2 + b^2):
+    // rho >= 0, so |b| <= r + rho and the argument is in [-1, 1] for every point — no octant swap, no reflection, no sign
+    // transfer (the octant form spent a min, a max3, a compare, a select and a v_bfi per point here), and its rsq is the one
+    // the gradient needs anyway (1 / s2 = rs2^2 instead of a v_rcp): 4.5 VALU instructions and one transcendental less per
+    // point-pose.  The polynomial's 8.7e-8 error is doubled: 1.7e-7 rad, below the fp32 ulp of the row coordinate.
+    // (+1e-37: keeps rsq and the quotient finite for a point AT the camera centre shifted by -eps; exact no-op otherwise.)
+    f2 s2 = pcl_fma2(b, b, o.rho2) + F2(1e-37f);
+    o.rs2 = (f2){__builtin_amdgcn_rsqf(s2.x), __builtin_amdgcn_rsqf(s2.y)};
+    f2 den = pcl_fma2(s2, o.rs2, rho);
+    f2 half_el = pcl_atan_poly2(b * (f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
     // sample_from_img (utils.py:97-98): g = (-phi/pi, -2 elev/pi) clipped to +-0.99, unnormalised (align_corners=False),
     // +1 for the zero border.  The clip is applied to the angles (|phi| <= 0.99 pi, |elev| <= 0.495 pi: the same set up to
     // the last ulp of the threshold) so the pixel coordinate is one fma from the angle.
-    const float lim_phi = 0.99f * 3.14159265358979323846f, lim_el = 0.495f * 3.14159265358979323846f;
+    const float lim_phi = 0.99f * 3.14159265358979323846f, lim_hel = 0.2475f * 3.14159265358979323846f;
     f2 phic = {__builtin_amdgcn_fmed3f(phi.x, -lim_phi, lim_phi), __builtin_amdgcn_fmed3f(phi.y, -lim_phi, lim_phi)};
-    f2 elc = {__builtin_amdgcn_fmed3f(elev.x, -lim_el, lim_el), __builtin_amdgcn_fmed3f(elev.y, -lim_el, lim_el)};
+    f2 helc = {__builtin_amdgcn_fmed3f(half_el.x, -lim_hel, lim_hel), __builtin_amdgcn_fmed3f(half_el.y, -lim_hel, lim_hel)};
     f2 ix = pcl_fma2(phic, F2(dm.k_ix), F2(dm.off_x));
-    f2 iy = pcl_fma2(elc, F2(dm.k_iy), F2(dm.off_y));
+    f2 iy = pcl_fma2(helc, F2(2.f * dm.k_iy), F2(dm.off_y));
     // ix, iy > 0 inside the border, so truncation == floor and fract == ix - floor(ix)
     pcl_issue_taps(tex, (int)ix.x, (int)iy.x, dm.Wp, o.ta);
     pcl_issue_taps(tex, (int)ix.y, (int)iy.y, dm.Wp, o.tb);
@@ -239,7 +249,7 @@ __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPose6& p
     // (a wave-uniform "no lane is clipped" fast path was tried: the extra basic block costs more in scheduling and
     // registers than the four selects it saves — 155 vs 141 us at cfg 2)
     o.in_phi0 = phi.x == phic.x; o.in_phi1 = phi.y == phic.y;
-    o.in_th0 = elev.x == elc.x; o.in_th1 = elev.y == elc.y;
+    o.in_th0 = half_el.x == helc.x; o.in_th1 = half_el.y == helc.y;
 }
 
 // Phase B: bilinear colour, mask, residual, gradient, accumulate.
@@ -314,9 +324,9 @@ __device__ __forceinline__ void pcl_sample2(const PclProj<FMT>& o, f2 ncr, f2 nc
         f2 dphi = (sx * F2(dm.k_phi)) * rphi, dth = (sy * F2(dm.k_theta)) * rth;
         // phi = atan2(py, a): dphi/dpx = -py/s1, dphi/dpy = a/s1 ; theta = atan2(rho, b): dth/drho = b/s2, dth/dpz = -rho/s2
         f2 a = px + F2(1e-6f), b = pz + F2(1e-6f), rho = o.rho2 * o.rinv;
-        f2 s1 = pcl_fma2(a, a, py * py), s2 = pcl_fma2(b, b, o.rho2);
+        f2 s1 = pcl_fma2(a, a, py * py);
         f2 ai = dphi * (f2){__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
-        f2 bi = dth * (f2){__builtin_amdgcn_rcpf(s2.x), __builtin_amdgcn_rcpf(s2.y)};
+        f2 bi = dth * (o.rs2 * o.rs2);                                            // dth / s2
         f2 k = b * bi * o.rinv;                                                   // (dL/drho) / rho
         f2 g0 = pcl_fma2(k, px, -(py * ai));
         f2 g1 = pcl_fma2(k, py, a * ai);
