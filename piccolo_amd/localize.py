@@ -116,7 +116,9 @@ def read_image(filename):
 
 
 def _to_img(img8, dev):
-    return (torch.from_numpy(img8).float() / 255.).to(dev)          # host division, like the reference (localize.py:169)
+    # host division, like the reference (localize.py:169); exactly k/255 by construction: tagged, so that packing it never waits
+    # for the device-side exactness check
+    return synth.mark_levels((torch.from_numpy(img8).float() / 255.).to(dev))
 
 
 def _fmt(a):

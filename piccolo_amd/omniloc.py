@@ -35,7 +35,7 @@ strict_reference_asserts = True
 # cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
 # An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
 # references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
-_CAPACITY = {"cloud": 2, "order": 2, "box": 4, "grid": 4, "pano": 16, "pano_u8": 4, "gd": 6, "trimgroups": 4}
+_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 4, "gd": 6, "trimgroups": 4}
 
 
 class _PackCache:

@@ -82,6 +82,7 @@ class Pano:
 
     def __init__(self, img, fmt="auto"):
         lib = _lib.load()
+        src = img
         img = _dev(img)
         if img.dim() != 3 or img.shape[2] != 3:
             raise ValueError("img must be (H, W, 3)")
@@ -99,7 +100,9 @@ class Pano:
             data = _bytes(lib.pcl_pano_bytes(self.H, self.W, code))
             flag = torch.zeros(1, dtype=torch.int32, device=img.device)
             _lib.check(getattr(lib, fn)(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), fn)
-            if int(flag.item()) == 0:
+            # an image tagged as k/255 by construction (synth.mark_levels: the harness's decoded image files) is not waited for:
+            # reading the flag is a blocking D2H copy per query image in front of a millisecond of work
+            if _known_levels(src) or int(flag.item()) == 0:
                 self.fmt, self.data = code, data
             elif fmt != "auto":
                 raise ValueError("image is not exactly k/255: cannot use %s texels" % fmt)
@@ -107,6 +110,13 @@ class Pano:
             self.fmt = _lib.PANO_F32
             self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_F32))
             _lib.check(lib.pcl_pano_pack(_ptr(img), self.H, self.W, _ptr(self.data), _stream()), "pcl_pano_pack")
+
+
+def _known_levels(img):
+    """True for a tensor tagged by synth.mark_levels (every value exactly k/255 by construction); PCL_VERIFY_LEVELS=1 ignores
+    the tag (the device-side check is then read back as for any other tensor)."""
+    tag = getattr(img, "_pcl_levels", None)
+    return tag is not None and torch.is_tensor(img) and tag == img._version and os.environ.get("PCL_VERIFY_LEVELS") != "1"
 
 
 def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
@@ -226,6 +236,7 @@ def color_match(img, template):
     """color_utils.color_match (color_utils.py:146-234) on the GPU: img (H,W,3) with levels k/255 -> matched (H,W,3).
     `template` is a ColorTemplate of the point colours."""
     lib = _lib.load()
+    known = _known_levels(img)
     img = _dev(img)
     H, W = int(img.shape[0]), int(img.shape[1])
     out = torch.empty_like(img)
@@ -234,7 +245,7 @@ def color_match(img, template):
     ws = _bytes(nws)
     _lib.check(lib.pcl_color_match(_ptr(img), H, W, _ptr(template.data), template.n, _ptr(out), _ptr(flag), _ptr(ws), nws,
                                    _stream()), "pcl_color_match")
-    if int(flag.item()):
+    if not known and int(flag.item()):
         raise ValueError("color_match: the panorama must hold levels k/255 (an image file's uint8 / 255); "
                          "found a non-black pixel channel in between")
     return out

@@ -90,4 +90,12 @@ def quantise_like_image_file(pano255):
     are mapped through a 256-entry table computed on the CPU."""
     import torch
     lut = (torch.arange(256, dtype=torch.float32) / 255.0).to(pano255.device)
-    return lut[pano255.clamp(0, 255).to(torch.int64)]
+    return mark_levels(lut[pano255.clamp(0, 255).to(torch.int64)])
+
+
+def mark_levels(img):
+    """Tag a float image tensor whose every value is exactly k/255 BY CONSTRUCTION (a decoded 8-bit image divided by 255 on the
+    host, a table lookup of such levels): the packers then take the level formats (fp16 / RGBA8 texels) without reading the
+    device-side exactness flag back — one blocking D2H copy per query image less.  Untagged tensors are checked as before."""
+    img._pcl_levels = img._version          # (an in-place change of the tensor afterwards voids the tag)
+    return img

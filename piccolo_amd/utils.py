@@ -136,8 +136,9 @@ def quantile(x, q):
 
 def out_of_room(xyz, trans, out_quantile=0.05):
     """True if `trans` (3,1) is outside the open [q, 1-q] quantile box of the cloud."""
-    from .omniloc import quantile_box_of             # the box is loop invariant: shared with omniloc / omniloc_batch
-    box = quantile_box_of(xyz, out_quantile).cpu()
+    from .omniloc import _cached, quantile_box_of    # the box is loop invariant: shared with omniloc / omniloc_batch
+    # (its host copy too: the dataset loops ask once per query image)
+    box = _cached("box", (xyz,), lambda: quantile_box_of(xyz, out_quantile).cpu(), sub=("host", float(out_quantile)))
     t = torch.as_tensor(trans).detach().cpu().reshape(3)
     inside = all(box[2 * k] < t[k] < box[2 * k + 1] for k in range(3))
     return not inside

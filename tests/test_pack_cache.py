@@ -74,3 +74,23 @@ def test_debug_visualize_host_helper(monkeypatch):
     assert shown == [1, 1, 1, 4, 2]
     with pytest.raises(ValueError):
         utils.debug_visualize([1, 2, 3])
+
+
+def test_levels_tag_follows_the_tensor_version():
+    """synth.mark_levels tags an image as 'every value exactly k/255 by construction' so that packing it never reads the
+    device-side exactness flag back; an in-place change afterwards voids the tag, PCL_VERIFY_LEVELS=1 ignores it (host logic)."""
+    import os
+    import torch
+    from piccolo_amd import ops, synth
+    img = synth.mark_levels(torch.randint(0, 256, (4, 8, 3)).float() / 255.0)
+    assert ops._known_levels(img)
+    assert not ops._known_levels(img.clone()) and not ops._known_levels(img.numpy())      # the tag belongs to this very tensor object
+    img[0, 0, 0] = 0.123
+    assert not ops._known_levels(img)                                                       # changed in place after tagging
+    img2 = synth.quantise_like_image_file(torch.rand(4, 8, 3) * 255)
+    assert ops._known_levels(img2) and bool((img2 * 255 == torch.round(img2 * 255)).all())
+    os.environ["PCL_VERIFY_LEVELS"] = "1"
+    try:
+        assert not ops._known_levels(img2)
+    finally:
+        del os.environ["PCL_VERIFY_LEVELS"]
