@@ -162,13 +162,20 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
         use_graph = cloud.n * B <= GRAPH_POINT_POSES
     use_graph = bool(use_graph) and vis_hook is None and not depth
 
-    def make():
-        return ops.GradientDescent(cloud, p0, trans, rot, box, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
+    def make(c=cloud):
+        return ops.GradientDescent(c, p0, trans, rot, box, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
                                    depth_mask=hyper[4], depth_tau=hyper[5])
     if not use_graph:
         gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
     else:
-        gd = _cached("gd", (xyz, rgb), make, sub=(B, p0.H, p0.W, p0.fmt) + hyper)
+        # One engine (state, workspace, captured graph) per POINT SET and launch shape.  The colours may change with every query
+        # image (color_mod / match_color give each image its own rgb): the engine owns a private copy of the packed cloud whose
+        # address the captured graph holds, and a cloud with other colours is copied into it (24 bytes per point on the device)
+        # instead of capturing a new graph per image.
+        gd = _cached("gd", (xyz,), lambda: make(ops.Cloud.private_copy(cloud)), sub=(B, p0.H, p0.W, p0.fmt) + hyper)
+        if getattr(gd, "_cloud_src", None) is not cloud:
+            gd.cloud.data.copy_(cloud.data)
+            gd._cloud_src = cloud
         gd.box.copy_(ops._dev(box).reshape(6))              # in place: the captured graph holds this buffer's address
         gd.reset(trans, rot)
     if len(panos) > 1 or use_graph:

@@ -69,6 +69,15 @@ class Cloud:
                    "pcl_cloud_pack")
         self.xyz = xyz          # kept for quantile_box (reads the reference's AoS layout)
 
+    @classmethod
+    def private_copy(cls, other):
+        """A Cloud with its own packed buffer holding `other`'s contents (same point order): for an engine whose captured graph
+        must keep one cloud address while the colours change from image to image."""
+        c = cls.__new__(cls)
+        c.n, c.order, c.xyz = other.n, other.order, other.xyz
+        c.data = other.data.clone()
+        return c
+
 
 class Pano:
     """Query panorama (H,W,3) float packed as zero-bordered texels.
@@ -172,8 +181,11 @@ def trim_loss_table(cloud, pano, trans, groups, return_count=False):
 
 def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
-    `cloud` is a packed Cloud.  Candidates are processed `batch` at a time (H*W*8 bytes of workspace each: the point lists
-    of the tile-binned render, or the z-buffer of the splat path).  return_parts: (scores, inter, nproj, nimg)."""
+    `cloud` is a packed Cloud.  Candidates are processed `batch` at a time.  Workspace per candidate: the point lists of the
+    tile-binned render (48 bytes per point in the worst case: 3 GB for 64 candidates at 1M points — HBM is there to be used),
+    or, where that path does not apply (more than 4096 image tiles, ...) or does not fit, H * W * 8 bytes for the z-buffer of the
+    splat path.  If the allocation fails the batch is halved, and the last resort is the splat path's small workspace.
+    return_parts: (scores, inter, nproj, nimg)."""
     lib = _lib.load()
     img = _dev(img)
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
@@ -182,15 +194,25 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
     inter = torch.empty(K, nblk, dtype=F32, device=img.device)
     nproj = torch.empty(K, nblk, dtype=torch.int32, device=img.device)
     nimg = torch.empty(nblk, dtype=torch.int32, device=img.device)
-    # workspace for the tile-binned render (48 B per point and candidate in the worst case): 3 GB for the 64 survivors of the
-    # loss trim at 1M points — one batch (four batches of 16: 2.0 instead of 1.7 ms; 0.8 instead of 0.5 ms at 167k points);
-    # a batch is kept within ~8 GB (10M points: 16 candidates at a time)
+    # one batch for the 64 survivors of the loss trim at 1M points (four batches of 16: 2.0 instead of 1.7 ms; 0.8 instead of
+    # 0.5 ms at 167k points); a batch is kept within ~8 GB (10M points: 16 candidates at a time).
+    # pcl_hist_trim_workspace_bytes_n is the binned path's size where that path will be taken, the splat path's otherwise.
     per_cand = max(lib.pcl_hist_trim_workspace_bytes_n(cloud.n, 1, H, W, num_split_h, num_split_w), 1)
     batch = max(1, min(batch, K, int(8e9 // per_cand)))
-    nws = lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w)
-    if nws == 0:
+    if lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w) == 0:
         raise ValueError("hist_trim_scores: need num_split_h >= 3 and blocks of at least one pixel")
-    ws = _bytes(nws)
+    ws = None
+    while ws is None:
+        nws = lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w)
+        try:
+            ws = _bytes(nws)
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            if batch > 1:
+                batch = (batch + 1) // 2
+                continue
+            nws = lib.pcl_hist_trim_workspace_bytes(1, H, W, num_split_h, num_split_w)      # the z-buffer splat path
+            ws = _bytes(nws)
     for k0 in range(0, K, batch):
         k1 = min(k0 + batch, K)
         _lib.check(lib.pcl_hist_trim_scores(_ptr(cloud.data), cloud.n, _ptr(img), H, W, _ptr(trans[k0:k1]),

@@ -407,6 +407,19 @@ def test_small_problems_replay_a_cached_graph_and_stay_bit_identical(oracle):
     m_graph = po.omniloc_batch_images(imgs, X, C, [t.clone() for t in trs], [r.clone() for r in ros], Cfg(**base))
     for a, b in zip(m_eager, m_graph):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # colours that change with every query image (color_mod / match_color hand each image its own rgb): still ONE engine per
+    # point set and launch shape — the new colours are copied into the engine's private packed cloud, whose address the captured
+    # graph holds — and the results are those of fresh eager launches on that cloud
+    n_eng = len(po._cache.kinds["gd"])
+    for scale in (0.9, 0.8, 0.9):
+        C2 = (C * scale).contiguous()
+        e2 = po.omniloc_batch(imgs[0], X, C2, trs[0].clone(), ros[0].clone(), Cfg(gd_graph=False, **base), {})
+        g2 = po.omniloc_batch(imgs[0], X, C2, trs[0].clone(), ros[0].clone(), Cfg(**base), {})
+        assert all(torch.equal(a, b) for a, b in zip(e2, g2)), scale
+        assert not torch.equal(e2[0], eager[0][0])                   # (other colours: another answer)
+    assert len(po._cache.kinds["gd"]) == n_eng
+    back = po.omniloc_batch(imgs[0], X, C, trs[0].clone(), ros[0].clone(), Cfg(**base), {})
+    assert all(torch.equal(a, b) for a, b in zip(eager[0], back))      # and the original colours again
 
 
 def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
