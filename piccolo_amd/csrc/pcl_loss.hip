@@ -86,6 +86,7 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
 
     // the poses this block evaluates, as SGPR pairs: straight from the pose records, or (FUSED) out of the optimiser update below
     PclPose6 P6[G];
+    unsigned PANO[G][2];                          // FUSED: the poses' panorama addresses as uniform values
     __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     // the cloud through a buffer resource too: 32-bit lane offsets + scalar plane offsets, no 64-bit address math
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
@@ -152,8 +153,15 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
             // poses of several query images may share a launch: each pose record can name its own panorama
             // (same size and texel format); scalar work only
             __amdgpu_buffer_rsrc_t tg = tex;
-            if (pr->pano_lo | pr->pano_hi) {
-                const void* pp = (const void*)(((unsigned long long)pr->pano_hi << 32) | (unsigned long long)pr->pano_lo);
+            unsigned pano_lo = pr->pano_lo, pano_hi = pr->pano_hi;
+            if constexpr (FUSED) {
+                // this kernel also STORES pose records (the block of chunk 0), so the compiler reads them with vector loads
+                // and would wrap every gather in a waterfall loop over a "divergent" texture descriptor (16 such loops: the
+                // first fused version was 17 us slower per launch at cfg 2): the address is uniform, say so
+                pano_lo = PANO[g][0]; pano_hi = PANO[g][1];
+            }
+            if (pano_lo | pano_hi) {
+                const void* pp = (const void*)(((unsigned long long)pano_hi << 32) | (unsigned long long)pano_lo);
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
@@ -178,6 +186,9 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
 #pragma unroll
             for (int k = 0; k < 12; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pose_sh[g][k])));
             P6[g] = PclPose6{(f2){v[0], v[1]}, (f2){v[2], v[3]}, (f2){v[4], v[5]}, (f2){v[6], v[7]}, (f2){v[8], v[9]}, (f2){v[10], v[11]}};
+            const PclPoseRec* pr = a.poses + (pose0 + g);
+            PANO[g][0] = (unsigned)__builtin_amdgcn_readfirstlane((int)pr->pano_lo);
+            PANO[g][1] = (unsigned)__builtin_amdgcn_readfirstlane((int)pr->pano_hi);
         }
     }
 
