@@ -336,6 +336,17 @@ def kernel_figures(N, B, groups, timed_per_run, kernel_ms, launches, pair_ms):
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBs": alg_bytes / (avg * 1e-3) / 1e9}
 
 
+def loss_kernel_name(lib, N, poses_per_launch, fmt_name):
+    """the dominant kernel of a launch chain as rocprofv3 lists it (pcl_gd_plan: poses per block, one or two launches per iteration)"""
+    import ctypes
+    G, fused = ctypes.c_int(0), ctypes.c_int(0)
+    lib.pcl_gd_plan(N, poses_per_launch, None, ctypes.byref(G), ctypes.byref(fused))
+    tex = {"u8": "RGBA8", "f16": "F16x4", "f32": "F32x4"}[fmt_name]
+    if fused.value:
+        return "pcl_loss_fused_kernel<G=%d, %s> (one launch per GD iteration: finishes the previous iteration in its prologue)" % (G.value, tex)
+    return "pcl_loss_kernel<G=%d, GRAD, %s>" % (G.value, tex)
+
+
 def valu_roof(roofs, N, poses_per_launch, avg_launch_ms):
     """The binding roof: wave64 VALU instructions per second of this run against one instruction per SIMD per 4 cycles."""
     wave_instr = roofs["valu_instr_per_point_pose"] * N * poses_per_launch / 64.0
@@ -374,6 +385,7 @@ def run_side(name, ranks, args, lib_hash, pair_ms, timer_stride, scenes, K, ipl,
         errs.append(synth.pose_errors(res_host[i, :3], R, gt[0], synth.rot_from_ypr_np(gt[1])))
     errs = np.array(errs)
     out = {"workload": "%d points, %dx%d, %d candidates, %d image(s) per launch chain" % (N, W, H, B, ipl),
+           "kernel": loss_kernel_name(_lib.load(), N, ipl * B, fmt),
            "value": B * K / elapsed, "unit": "candidate-poses/s", "ms_per_step": elapsed / K * 1e3, "steps": K, "passes": len(times),
            "poses_per_launch": ipl * B, "texels": fmt, "avg_launch_ms": kf["avg_launch_ms"],
            "us_per_iteration": elapsed / (K / ipl) / NUM_ITER * 1e6,
@@ -548,7 +560,7 @@ def main():
                        "is": "SURVEY.md 8(d)'s ALGORITHMIC figure: 24 B x points x poses per launch / kernel time.  Not a bandwidth and no "
                              "longer a roof: a block reads its cloud chunk once for the two poses it evaluates, out of L2, so the figure "
                              "can pass 1.0 while the measured memory-side traffic is ~5 % of the HBM peak"}
-        kernel_name = "pcl_loss_kernel<G=%d, GRAD, %s>" % (2 if (B * ipl) % 2 == 0 else 1, {"u8": "RGBA8", "f16": "F16x4", "f32": "F32x4"}[fmt_name])
+        kernel_name = loss_kernel_name(lib, N, B * ipl, fmt_name)
         common = {"kernel": kernel_name, "traffic": traffic, "traffic_key": roofs_key,
                   "avg_launch_ms": kf["avg_launch_ms"], "avg_launch_ms_raw_events": kf["avg_launch_ms_raw"],
                   "event_pair_ms_subtracted": pair_ms, "launches_timed": launches,

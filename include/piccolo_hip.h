@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_* */
+#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -141,6 +141,11 @@ int pcl_gd_run(const float *cloud, int64_t n, const void *pano, int pano_format,
                const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
                size_t workspace_bytes, void *timer, void *stream);
 int pcl_gd_result(const void *state, int B, float *result, void *stream);
+/* How pcl_gd_run decomposes an n-point, B-candidate problem (host-only query, measurement aid): chunks of the cloud, poses per
+ * block, and whether an iteration is ONE launch (the loss launch of iteration k + 1 finishes iteration k in the prologue of every
+ * block: launches whose chunk x group blocks are all resident at once — the reference's shipped 167k-point / 6-candidate shape)
+ * or two (loss + epilogue).  Any of the three outputs may be NULL. */
+int pcl_gd_plan(int64_t n, int B, int *nchunks_host, int *poses_per_block_host, int *fused_host);
 /* Several query images against one shared cloud in ONE launch chain (BASELINE cfg 4: independent panoramas, shared
  * cloud): candidate b samples panos[b] (device array of B device addresses of packed panoramas; all the same H, W and
  * texel format as the `pano` passed to pcl_gd_run, which stays the default for entries that are 0).  Call after

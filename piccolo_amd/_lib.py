@@ -72,6 +72,7 @@ SIGNATURES = {
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
     "pcl_timer_calibrate": (_int, [_vp, _int, _c.POINTER(_dbl), _vp]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
+    "pcl_gd_plan": (_int, [_i64, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),
     "pcl_sample_from_img": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp]),

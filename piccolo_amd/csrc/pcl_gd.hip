@@ -211,6 +211,21 @@ extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_
     return 0;
 }
 
+static int gd_fuse_limit()
+{
+    const char* fuse_env = getenv("PCL_GD_FUSE_BLOCKS");          // (read per call: tests run both forms in one process)
+    return fuse_env && *fuse_env ? atoi(fuse_env) : 1024;
+}
+
+extern "C" int pcl_gd_plan(int64_t n, int B, int* nchunks_host, int* poses_per_block_host, int* fused_host)
+{
+    if (n <= 0 || n > PCL_MAX_POINTS || B <= 0) return PCL_EINVAL;
+    if (nchunks_host) *nchunks_host = pcl_plan_nchunks(n, B);
+    if (poses_per_block_host) *poses_per_block_host = pcl_plan_G(n, B);
+    if (fused_host) *fused_host = pcl_plan_nblocks(n, B) <= gd_fuse_limit() ? 1 : 0;
+    return 0;
+}
+
 extern "C" int pcl_timer_calibrate(void* timer, int reps, double* pair_ms_host, void* stream)
 {
     if (!timer || !pair_ms_host || reps <= 0 || reps > 4096) return PCL_EINVAL;
@@ -272,8 +287,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     // (PclFuseArgs) — no inter-block synchronisation, the kernel boundary is the only one; the last iteration is finished by
     // the stand-alone epilogue.  Same arithmetic in the same order: results are bit-identical to the two-launch form
     // (PCL_GD_FUSE_BLOCKS: largest grid that takes this path, 0 = never).
-    const char* fuse_env = getenv("PCL_GD_FUSE_BLOCKS");          // (read per call: tests run both forms in one process)
-    const int fuse_blocks = fuse_env && *fuse_env ? atoi(fuse_env) : 1024;
+    const int fuse_blocks = gd_fuse_limit();
     const bool fused = !visible && pcl_plan_nblocks(n, B) <= fuse_blocks;
     const int G = pcl_plan_G(n, B);
     auto epilogue = [&](int it, int copy_in, float* partials) {
