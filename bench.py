@@ -147,7 +147,7 @@ def lookup_roofs(path, workload, poses_per_launch, fmt_name, lib_hash):
 class Ranks:
     """The process group of the run (None for one process): barrier, the result gather, MAX over ranks."""
 
-    def __init__(self, args, dev_holder):
+    def __init__(self, args):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -454,7 +454,7 @@ def main():
                     help="per-launch-shape counter figures from the rocprofv3 PMC passes (profiles/collect.sh)")
     args = ap.parse_args()
 
-    ranks = Ranks(args, None)
+    ranks = Ranks(args)
     rank, world, dev = ranks.rank, ranks.world, ranks.dev
     lib = _lib.load()
     lib_hash = lib.pcl_source_hash().decode()
