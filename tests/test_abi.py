@@ -134,3 +134,31 @@ def test_every_entry_point_rejects_null_arguments_before_touching_a_device():
     assert not wrong, wrong
     # handle-returning / void functions: called with nulls above without a crash, nothing to compare
     assert set(skipped) <= {"pcl_timer_create", "pcl_timer_destroy", "pcl_timer_reset", "pcl_timer_set_stride"}, skipped
+
+
+def test_gd_plan_reports_the_decomposition_host_only():
+    """pcl_gd_plan (host-only query): chunks, poses per block and whether an iteration is one launch (all chunk x group blocks
+    resident at once: the reference's shipped 167k-point / 6-candidate shape, cfg 1) or two (cfg 2 and larger)."""
+    import ctypes
+    from piccolo_amd import _lib
+    lib = _lib.load()
+
+    def plan(n, B):
+        c, g, f = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.pcl_gd_plan(n, B, ctypes.byref(c), ctypes.byref(g), ctypes.byref(f)) == 0
+        return c.value, g.value, f.value
+    old = os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
+    try:
+        c, g, f = plan(166_667, 6)
+        assert g == 2 and f == 1 and c % 8 == 0 and c * 3 <= 1024            # 3 pose groups x chunks: all resident
+        assert plan(100_000, 1)[1:] == (1, 1)                                # cfg 1: one pose per block, fused
+        c, g, f = plan(1_000_000, 32)
+        assert (c, g, f) == (256, 2, 0)                                      # cfg 2: 4096 blocks, two launches per iteration
+        assert plan(1_000_000, 256)[2] == 0 and plan(10_000_000, 64)[2] == 0
+        os.environ["PCL_GD_FUSE_BLOCKS"] = "0"                               # read per call
+        assert plan(166_667, 6)[2] == 0
+    finally:
+        os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
+        if old is not None:
+            os.environ["PCL_GD_FUSE_BLOCKS"] = old
+    assert lib.pcl_gd_plan(0, 6, None, None, None) == -1 and lib.pcl_gd_plan(1000, 4, None, None, None) == 0
