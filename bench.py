@@ -372,7 +372,11 @@ def run_side(name, ranks, args, lib_hash, pair_ms, timer_stride, scenes, K, ipl,
     timer = ops.KernelTimer(m.timed_per_run * (K + 1), stride=m.stride)
     m.refine(witems[0], results)
     torch.cuda.synchronize()
-    times, elapsed, (kernel_ms, launches) = m.repeated(items, results, K, timer, min_seconds, with_gather=False)
+    # wall time WITHOUT the kernel timer (an event pair around every 10th launch costs ~0.7 us per iteration: 6 % of a 12 us
+    # iteration at the shipped shape, nothing at cfg 2), then one timed pass for the launch time
+    times, elapsed, _ = m.repeated(items, results, K, None, min_seconds, with_gather=False)
+    m.timed_pass(items, results, K, timer, False)
+    kernel_ms, launches = timer.read()
     groups = [it[1] for it in items]
     kf = kernel_figures(N, B, groups, m.timed_per_run, kernel_ms, launches, pair_ms)
     fmt = FMT_NAMES[sc.image(0)["pano"].fmt]
