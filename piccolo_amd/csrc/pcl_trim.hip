@@ -3,15 +3,15 @@
 //
 // The reference loops K * R forwards in Python (utils.py:484-499: p = R (x - t) -> cloud2idx -> sample_from_img -> mask ->
 // mean ||c - rgb||).  The candidate rotations are a GRID (utils.py:321-360): yaw x pitch x roll, R = RZ(yaw) RY(pitch) RX(roll).
-// For q' = RY RX (x - t):  p = RZ(yaw) q'  has  p_z = q'_z  and  p_x^2 + p_y^2 = q'_x^2 + q'_y^2, so
-//     theta = atan2(rho, p_z + eps)                    does not depend on yaw at all (panorama row and its fraction shared),
-//     phi   = atan2(p_y, p_x + eps) = phi0 + yaw - eps p_y / rho^2 + O(eps^2 / rho^2),   phi0 = atan2(q'_y, q'_x)
+// Write R = RZ(delta) M (M: any rotation of R's class, see below) and q' = M (x - t):  p = RZ(delta) q'  has  p_z = q'_z  and
+// p_x^2 + p_y^2 = q'_x^2 + q'_y^2, so
+//     theta = atan2(rho, p_z + eps)                    does not depend on delta at all (panorama row and its fraction shared),
+//     phi   = atan2(p_y, p_x + eps) = phi0 + delta - eps p_y / rho^2 + O(eps^2 / rho^2),   phi0 = atan2(q'_y, q'_x)
 // (first-order carry of the reference's `x + 1e-6`, utils.py:48-51; eps / rho < 1e-2 for every point farther than 0.1 mm from the
 // camera's vertical axis — waves that hold a nearer point evaluate phi exactly, see `tiny` below).  A block therefore rotates,
-// normalises and takes BOTH atan2s once per point for up to PCL_TRIM_Y yaws of one (pitch, roll) class and per yaw only
-// shifts the column, gathers and accumulates: measured VALU instructions per point-pose 78.5 (generic forward kernel) ->
-// see DESIGN.md §4.6.  configs of the reference: omniscenes.ini is yaw_only with 8 yaws (one class per translation), the
-// Stanford grids give 24 distinct rotations in classes of up to four yaws.
+// normalises and takes BOTH atan2s once per point for up to PCL_TRIM_Y yaws of one class and per yaw only computes p_y, shifts
+// the column, gathers and accumulates: 51.5 VALU instructions per point-pose on the reference's grids against 78.5 of the generic
+// forward kernel (profiles/r03/t_trim_bench_*; DESIGN.md §4.6 — with that the kernel is bound by the texture path).
 //
 // Which rotations share: R_a and R_b differ by a yaw — R_b = RZ(delta) R_a — exactly when their THIRD ROWS are equal (RZ leaves
 // the z row alone).  Equal (pitch, roll) is the obvious case; the reference's 3-DoF grid of quarter turns (24 distinct rotations out
@@ -28,7 +28,7 @@
 #define PCL_TRIM_Y 4        // yaws evaluated per loaded point pair (partials row = PCL_TRIM_Y x {sum ||d||, count} = PCL_NACC floats)
 static_assert(2 * PCL_TRIM_Y == PCL_NACC, "a trim partials row has the size of a loss partials row");
 
-// One (pitch, roll) class of rotations, up to PCL_TRIM_Y of its yaws — read through scalar loads.
+// One class of rotations (equal third row), up to PCL_TRIM_Y of its members — read through scalar loads.
 struct PclTrimGroup {
     float ns[PCL_TRIM_Y], nc[PCL_TRIM_Y]; // -sin / -cos of the member's yaw relative to the class's first rotation
     float turn[PCL_TRIM_Y];               // 0.5 - yaw / 2 pi, that yaw reduced to [0, 2 pi): in (-0.5, 0.5]
