@@ -779,12 +779,46 @@ def g21_full_size_batch_loss():
          xyz_sum=float(xyz.astype(np.float64).sum()), rgb_sum=float(rgb.astype(np.float64).sum()), **res)
 
 
+# ----------------------------------------------------------------------------- G22
+def g22_shipped_shape_end_to_end():
+    """The reference's omniloc_batch, full 100 iterations, at the sizes of its SHIPPED config (configs/stanford_parallel.ini:
+    1M points / sample_rate 6 = 166 667 points, 2048x1024 panorama, num_input 6, lr 0.1, patience 5, factor 0.8) on 4 scenes,
+    each run twice (original and permuted point order: the reference's own fp32 self-noise).  On the device this shape runs ONE
+    launch per GD iteration (fused prologue, csrc/pcl_loss.hip).  Panoramas from the deterministic oracle renderer (checksums kept).
+    ~45 s per run on 4 threads."""
+    from oracle import oracle as orc
+    N, H, W, S, B = 166_667, 1024, 2048, 4, 6
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, visualize=False, num_input=B)
+    rows, sums = [], []
+    for s in range(S):
+        seed = 700 + s
+        xyz, rgb = synth.box_room(N, seed=seed)
+        t_gt, ypr_gt = synth.gt_pose(seed)
+        img_u8 = orc.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W))
+        sums.append(int(img_u8.astype(np.int64).sum()))
+        img = img_u8.astype(np.float32) / 255.0
+        trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=seed)
+        R_gt = synth.rot_from_ypr_np(ypr_gt)
+        perm = np.random.default_rng(2000 + s).permutation(N)
+        out = []
+        for x, c in ((xyz, rgb), (xyz[perm], rgb[perm])):
+            r = ref_omniloc.omniloc_batch(torch.from_numpy(img), torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(trans.copy()),
+                                          torch.from_numpy(rot.copy()), cfg, {})
+            t, R = r[0].detach().numpy().reshape(3), r[1].detach().numpy()
+            out.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+        rows.append(np.stack(out))
+        print("G22 seed %d t_err %.4f / %.4f (perm)  r_err %.3f / %.3f  loss %.5f / %.5f" % (
+            seed, rows[-1][0, 13], rows[-1][1, 13], rows[-1][0, 14], rows[-1][1, 14], rows[-1][0, 12], rows[-1][1, 12]), flush=True)
+    # columns: t(3) R(9) loss t_err r_err ; axis 1: original / permuted point order
+    save("g22_shipped_shape.npz", N=N, H=H, W=W, B=B, seed0=700, batch=np.stack(rows), img_sum=np.array(sums))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
             g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils,
             g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks,
-            g20_standalone_backward, g21_full_size_batch_loss]
+            g20_standalone_backward, g21_full_size_batch_loss, g22_shipped_shape_end_to_end]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

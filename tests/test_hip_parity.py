@@ -819,6 +819,40 @@ def test_end_to_end_32_seeds_as_close_to_the_reference_as_it_is_to_itself(ops, o
     g18_compare(np.array(rows_b), g["batch"], lambda q, a, b, y=None: parity("omniloc_batch: " + q, a, b, y))
 
 
+def test_shipped_shape_end_to_end_as_close_to_the_reference_as_it_is_to_itself(ops, oracle, parity):
+    """G22: the reference's omniloc_batch at the sizes of its SHIPPED config (166 667 points, 2048x1024, 6 candidates, 100
+    iterations), 4 scenes, each also rerun by the reference with the points permuted.  On the device this is the shape that runs
+    ONE launch per GD iteration (fused prologue): the free-running result must land as close to the reference as the reference
+    lands to itself — with the fused path and with it switched off (the two are bit-identical)."""
+    import os
+    from piccolo_amd import _lib
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    from test_oracle_golden import g22_compare, g22_scene
+    g = load_golden("g22_shipped_shape.npz")
+    B = int(g["B"])
+    import ctypes
+    fz = ctypes.c_int(-1)
+    assert _lib.load().pcl_gd_plan(int(g["N"]), B, None, None, ctypes.byref(fz)) == 0 and fz.value == 1     # this shape takes the fused path
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=B)
+    rows, rows_two = [], []
+    for s in range(g["batch"].shape[0]):
+        xyz, rgb, img, trans, rot, t_gt, R_gt = g22_scene(oracle, g, s)
+        X, C, I = T(xyz), T(rgb), T(img)
+        r = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), cfg, {})
+        t, R = r[0].numpy().reshape(3), r[1].numpy()
+        rows.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+        os.environ["PCL_GD_FUSE_BLOCKS"] = "0"
+        try:
+            po._cache.clear()
+            r2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(gd_graph=False, **cfg.__dict__), {})
+        finally:
+            del os.environ["PCL_GD_FUSE_BLOCKS"]
+            po._cache.clear()
+        assert all(torch.equal(a, b) for a, b in zip(r, r2)), s
+    g22_compare(np.array(rows), g["batch"], parity)
+
+
 def test_cloud_order_is_a_morton_sorted_permutation(ops):
     """pcl_cloud_order (bounding box, 63-bit keys and radix sort on the device): a permutation whose Morton keys,
     recomputed here from the same quantisation, are non-decreasing; equal keys keep their input order (stable)."""

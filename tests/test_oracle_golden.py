@@ -376,6 +376,49 @@ def test_oracle_at_full_cfg2_size_equals_the_reference(oracle, parity):
                2 * gap_ref, gap_ref)
 
 
+# G22 -----------------------------------------------------------------------------------------
+def g22_scene(oracle, g, s):
+    """Scene s of G22 (the reference's SHIPPED shape: 166 667 points, 2048x1024, 6 candidates), regenerated from its seed."""
+    from piccolo_amd import synth
+    N, H, W, B, seed = int(g["N"]), int(g["H"]), int(g["W"]), int(g["B"]), int(g["seed0"]) + s
+    xyz, rgb = synth.box_room(N, seed)
+    t_gt, ypr_gt = synth.gt_pose(seed)
+    img_u8 = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W))
+    assert int(img_u8.astype(np.int64).sum()) == int(g["img_sum"][s]), "G22 panorama %d differs from the generator's" % s
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=seed)
+    return xyz, rgb, img_u8.astype(np.float32) / 255.0, trans, rot, t_gt, synth.rot_from_ypr_np(ypr_gt)
+
+
+def g22_compare(rows, ref, record):
+    """rows (S, 15) of this implementation vs ref (S, 2, 15): the reference's omniloc_batch and its permuted-order rerun.  Four
+    scenes: every scene is held to the reference's OWN run-to-run distance (worst scene of the reference, x 2.5, + a floor)."""
+    self_t, self_r = np.abs(ref[:, 0, 13] - ref[:, 1, 13]), np.abs(ref[:, 0, 14] - ref[:, 1, 14])
+    self_p = np.abs(ref[:, 0, :3] - ref[:, 1, :3]).max(1)
+    d_t, d_r = np.abs(rows[:, 13] - ref[:, 0, 13]), np.abs(rows[:, 14] - ref[:, 0, 14])
+    d_p = np.abs(rows[:, :3] - ref[:, 0, :3]).max(1)
+    record("t-err distance to the reference, worst of 4 scenes (m)", d_t.max(), 2.5 * self_t.max() + 5e-4, self_t.max())
+    record("R-err distance to the reference, worst of 4 scenes (deg)", d_r.max(), 2.5 * self_r.max() + 1e-2, self_r.max())
+    record("recovered translation vs the reference's, worst of 4 scenes (m)", d_p.max(), 2.5 * self_p.max() + 5e-4, self_p.max())
+    record("final loss vs the reference's, worst of 4 scenes (rel)", (np.abs(rows[:, 12] - ref[:, 0, 12]) / ref[:, 0, 12]).max(),
+           2.5 * (np.abs(ref[:, 1, 12] - ref[:, 0, 12]) / ref[:, 0, 12]).max() + 1e-4)
+
+
+def test_oracle_at_the_shipped_shape_within_reference_self_noise(oracle, parity):
+    """G22: the reference's omniloc_batch at the sizes of its shipped config, 100 iterations, 4 scenes x (original, permuted).
+    The oracle's restatement, free-running, lands as close to the reference as the reference lands to itself."""
+    from oracle import gd
+    from piccolo_amd import synth
+    g = load_golden("g22_shipped_shape.npz")
+    cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=int(g["B"]))
+    rows = []
+    for s in range(g["batch"].shape[0]):
+        xyz, rgb, img, trans, rot, t_gt, R_gt = g22_scene(oracle, g, s)
+        r = gd.omniloc_batch(img, xyz, rgb, trans.copy(), rot.copy(), cfg)
+        t, R = r[0].reshape(3), r[1]
+        rows.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+    g22_compare(np.array(rows), g["batch"], parity)
+
+
 # G12 -----------------------------------------------------------------------------------------
 def test_trim_input_hist_secondary(oracle):
     """Oracle vs the reference's block-histogram scores.  The rendered panoramas differ from the reference's in the
