@@ -400,15 +400,17 @@ def run_side(name, ranks, args, lib_hash, pair_ms, timer_stride, scenes, K, ipl,
     return out
 
 
-def pipeline_block(sc, n_images=3):
-    """The whole per-image pipeline at cfg-2 size through the product's call surface — what the reference's `time (s)` CSV column
-    measures (localize.py:208,222-223): make_input (1800-pose grid -> loss trim to 64 -> histogram trim to 32) + omniloc_batch
-    (32 candidates x 100 iterations); medians over `n_images` query images after one untimed image."""
+def pipeline_block(sc, n_images=3, num_input=32, num_intermediate=64):
+    """The whole per-image pipeline through the product's call surface — what the reference's `time (s)` CSV column measures
+    (localize.py:208,222-223): make_input (1800-pose grid -> loss trim to `num_intermediate` -> histogram trim to `num_input`) +
+    omniloc_batch (`num_input` candidates x 100 iterations); medians over `n_images` query images after one untimed image.
+    cfg-2 size: 1M points, 64 -> 32; the reference's shipped stanford_parallel.ini: 166 667 points, 50 -> 6."""
     from piccolo_amd import omniloc as po
     from piccolo_amd import utils
 
     class Cfg:
-        lr, num_iter, patience, factor, out_of_room_quantile, num_input = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE, 32
+        lr, num_iter, patience, factor, out_of_room_quantile = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE
+    Cfg.num_input = num_input
 
     rows = []
     for j in range(n_images + 1):
@@ -416,7 +418,7 @@ def pipeline_block(sc, n_images=3):
         img = e["img"]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr, ro = utils.make_input(img, sc.X, sc.C, 32, STANFORD_INIT, "loss_histogram", 64)
+        tr, ro = utils.make_input(img, sc.X, sc.C, num_input, STANFORD_INIT, "loss_histogram", num_intermediate)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res = po.omniloc_batch(img, sc.X, sc.C, tr, ro, Cfg(), {})
@@ -427,8 +429,8 @@ def pipeline_block(sc, n_images=3):
             rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, te, re))
         del e["img"]
     rows = np.array(rows)
-    return {"what": "per query image at cfg-2 size (1M points, 2048x1024): make_input (75 x 24 = 1800-pose grid -> 64 -> 32) + "
-                    "omniloc_batch (32 candidates x 100 iterations), medians over %d images" % n_images,
+    return {"what": "per query image (%d points, %dx%d): make_input (75 x 24 = 1800-pose grid -> %d -> %d) + omniloc_batch (%d candidates x "
+                    "100 iterations), medians over %d images" % (sc.N, sc.W, sc.H, num_intermediate, num_input, num_input, n_images),
             "make_input_ms": float(np.median(rows[:, 0])), "refine_ms": float(np.median(rows[:, 1])),
             "total_ms": float(np.median(rows[:, 0] + rows[:, 1])),
             "median_t_err_m": float(np.median(rows[:, 2])), "median_r_err_deg": float(np.median(rows[:, 3]))}
@@ -615,6 +617,8 @@ def main():
                 also["shipped_8_images_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=8)
                 if (1_000_000, 1024, 2048) in scenes:
                     also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
+                if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
+                    also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
                 if args.workload != "cfg5":
                     also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
             except Exception as exc:                        # the headline must survive a failing side measurement
