@@ -9,7 +9,8 @@ HBM before the timed region starts.  Independent query images are sharded round-
 every rank refines `steps` images); the only collective is the final all_gather of the results (RCCL).
 
     python bench.py                                   # 1 GPU, cfg2 (1M points, 2048x1024, 32 candidates)
-    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W
+    python bench.py --gpus 8 --steps K --warmup W     # starts 8 fresh rank processes itself (self_launch) and relays rank 0's line
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W     # or under torchrun
 
 The JSON line:
   value / ms_per_step         default mode: 256 // B query images share one launch chain (cfg 4's shape on one GPU)
@@ -38,10 +39,66 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the LAUNCHER.  It starts
+    N fresh rank processes (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+    bench.py <same arguments>`: what the driver's own N > 1 command line is), waits, relays rank 0's JSON line as the last line
+    of its own stdout and exits with the children's status.  It runs BEFORE torch or the HIP library are imported — the
+    launcher never touches the GPU (stdlib only) and nothing here replaces a running program (`subprocess`, never `os.exec*`).
+    Returns None when this process is an ordinary rank (N == 1, or started by torch.distributed.run)."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = argv[i + 1]
+        elif a.startswith("--gpus="):
+            n = a.split("=", 1)[1]
+    try:
+        n = int(n)
+    except ValueError:
+        return None                                          # argparse will complain
+    if n <= 1 or "WORLD_SIZE" in os.environ or "-h" in argv or "--help" in argv:
+        return None
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:                           # a free port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")                   # (torchrun would set it, with a warning; cpu_baseline sizes its own pool)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, "--", os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=os.getcwd())
+    last_json = None
+    for ln in child.stdout:                                  # everything the ranks print goes to stderr as it comes ...
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            last_json = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    sys.stderr.flush()
+    if last_json is not None:                                # ... and rank 0's line is the one line on stdout
+        print(last_json, flush=True)
+    if rc == 0 and last_json is None:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
 sys.path.insert(0, REPO)
 
 from piccolo_amd import _lib, ops, synth  # noqa: E402
@@ -443,6 +500,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="size of the CPU sample (seconds of pose evaluations)")
     ap.add_argument("--no-single-image", action="store_true", help="skip the one-image-per-launch-chain pass")
     ap.add_argument("--no-also", action="store_true", help="skip the `also` block (cfg 3, cfg 5, shipped shape, per-image pipeline)")
     ap.add_argument("--images-per-launch", type=int, default=0,
@@ -594,8 +652,10 @@ def main():
             "metric": "candidate-poses/s", "value": value, "unit": "candidate-poses/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD iterations per query image"
-                                   % (args.workload, N, W, H, B, NUM_ITER),
+            "config": {"workload": "%s x %d query images per launch chain%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD "
+                                   "iterations per query image, %d poses per launch; the literal one-image-per-chain %s is `single_image`"
+                                   % (args.workload, ipl, " (cfg 4's shape on one GPU)" if args.workload == "cfg2" and ipl > 1 else "",
+                                      N, W, H, B, NUM_ITER, ipl * B, args.workload),
                        "images_per_gpu": K, "sharding": "query images round-robin over ranks, RCCL all_gather of results",
                        "mode": "omniloc_batch" if batch_mode else "omniloc", "images_per_launch": ipl,
                        "poses_per_launch": ipl * B, "texels": fmt_name, "warmup_images": "distinct from the timed ones"},
@@ -607,26 +667,6 @@ def main():
             "roofline": roofline,
             "checks": checks,
         }
-        if not args.no_also and world == 1:
-            also = {}
-            t_also = time.perf_counter()
-            try:
-                if args.workload != "cfg3":
-                    also["cfg3"] = run_side("cfg3", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=1)
-                also["shipped_1_image_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=1)
-                also["shipped_8_images_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=8)
-                if (1_000_000, 1024, 2048) in scenes:
-                    also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
-                if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
-                    also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
-                if args.workload != "cfg5":
-                    also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
-            except Exception as exc:                        # the headline must survive a failing side measurement
-                also["error"] = "%s: %s" % (type(exc).__name__, exc)
-            also["seconds"] = time.perf_counter() - t_also
-            line["also"] = also
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(sc.xyz, sc.rgb, img0_host, start0_host[0], start0_host[1])
     # RCCL prints its version banner through C stdio, which is flushed at exit — after Python's own output.  Every rank
     # flushes it now, before the last barrier, so that rank 0's JSON line is the last thing the job writes to stdout.
     try:
@@ -638,8 +678,39 @@ def main():
     if ranks.dist is not None:
         ranks.dist.barrier()
         ranks.dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+        ranks.dist = None
+    if rank != 0:
+        return
+    # ---- rank 0 alone from here on (the job's timed region and its final barrier are behind; the other ranks have left):
+    # side measurements and the CPU baseline, so that an N > 1 line carries them too
+    if world > 1:
+        # the N = 1 value of THIS build on THIS node, for the driver's N = 1 record to be checked against: the same timed pass
+        # (rank 0's K images, same launch shape) with no other rank running
+        n1_times, n1_elapsed, _ = m.repeated(timed_items, results, K, None, min(args.min_seconds, 1.0), with_gather=False)
+        line["n1_value_same_build"] = {"value": B * K / n1_elapsed, "ms_per_step": n1_elapsed / K * 1e3, "passes": len(n1_times),
+                                       "is": "rank 0 alone after the job's final barrier: the same K steps at the same launch shape "
+                                             "with the other ranks gone; value / n_gpus against this is the per-rank efficiency"}
+    if not args.no_also:
+        also = {"measured_by": "rank 0 alone, after the timed region%s" % (" and the job's final barrier (reduced set)" if world > 1 else "")}
+        t_also = time.perf_counter()
+        try:
+            if args.workload != "cfg3" and world == 1:
+                also["cfg3"] = run_side("cfg3", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=1)
+            also["shipped_1_image_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=1)
+            also["shipped_8_images_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=8)
+            if (1_000_000, 1024, 2048) in scenes and world == 1:
+                also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
+            if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
+                also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
+            if args.workload != "cfg5" and world == 1:
+                also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
+        except Exception as exc:                        # the headline must survive a failing side measurement
+            also["error"] = "%s: %s" % (type(exc).__name__, exc)
+        also["seconds"] = time.perf_counter() - t_also
+        line["also"] = also
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(sc.xyz, sc.rgb, img0_host, start0_host[0], start0_host[1], budget_s=args.cpu_baseline_seconds)
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

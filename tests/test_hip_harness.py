@@ -261,6 +261,46 @@ def test_bench_rccl_path_at_world_size_one():
     assert d["checks"]["kernel_time_within_step"] and "also" not in d
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` as the driver calls the N = 1 bench, no torchrun around it (localize.py:143,357: the query
+    images are what is sharded): the launcher process starts two fresh ranks before it has touched the GPU, the ranks share the
+    one GPU over gloo, and the launcher's stdout is exactly rank 0's JSON line — a COMPLETE one: cpu_baseline, a reduced `also`
+    block and the N = 1 value of the same build are measured by rank 0 after the job's final barrier."""
+    import os
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2", "--warmup", "1",
+           "--min-seconds", "0.2", "--cpu-baseline-seconds", "2"]
+    env = {"PCL_DIST_BACKEND": "gloo"}
+    assert "WORLD_SIZE" not in os.environ
+    d = _run_bench(cmd, env)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["unit"] == "candidate-poses/s"
+    n1 = d["n1_value_same_build"]
+    assert n1["value"] > 0 and d["value"] > 0
+    also = d["also"]
+    assert "error" not in also, also
+    assert also["pipeline_shipped"]["total_ms"] > 0 and also["shipped_8_images_per_chain"]["value"] > 0
+    assert "cfg5" not in also and "cfg3" not in also          # the reduced set of an N > 1 line
+    assert d["roofline"]["frac"] > 0 and d["single_image"]["value"] > 0
+
+
+def test_bench_launcher_relays_the_ranks_refusal():
+    """The same command line with the default back end (RCCL: one GPU per rank) on a box with fewer GPUs than ranks: every
+    rank refuses with the "visible" message, the launcher exits non-zero and prints no JSON line."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PCL_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1), "--workload", "cfg1", "--steps", "2",
+                          "--warmup", "1"], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "visible" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """--gpus N with fewer than N visible devices (RCCL needs one GPU per rank): a clear message, no hang."""
     import os
