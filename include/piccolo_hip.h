@@ -232,7 +232,10 @@ int pcl_hist_trim_reduce(const float *inter, const int32_t *nproj, const int32_t
  *   pcl_trim_groups: classes of equal (pitch, roll) of the rotation table (bitwise), built on the device into
  *     `groups` (pcl_trim_groups_bytes(R) bytes; its first int32 is the number of 4-yaw groups, which a caller may read back ONCE
  *     per rotation grid and pass as `ngroups`; passing R is always valid: surplus blocks return at once).
- *   pcl_trim_loss: workspace pcl_trim_loss_workspace_bytes(n, K, ngroups). */
+ *     R <= 1024 (PCL_EINVAL beyond: callers fall back to pcl_sampling_loss over the K x R pairs, as piccolo_amd/utils.py does).
+ *   pcl_trim_loss: workspace pcl_trim_loss_workspace_bytes(n, K, ngroups).  The table is filled with NaN first; if `groups` was
+ *     built from a table of another size, or holds more groups than `ngroups`, NOTHING is written over them: an entry the
+ *     launch did not compute ranks last in the caller's selection (NaN), never as stale memory. */
 size_t pcl_trim_groups_bytes(int R);
 int pcl_trim_groups(const float *rot, int R, void *groups, void *stream);
 size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups);

@@ -369,6 +369,9 @@ __global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __res
     if (id >= nslots * PCL_TRIM_Y) return;
     const int slot = id / PCL_TRIM_Y, y = id - slot * PCL_TRIM_Y;
     const int g = slot / K, k = slot - g * K;
+    // a `groups` blob of another rotation table, or more groups than the caller launched: nothing is written and the table
+    // keeps the NaNs pcl_trim_loss filled it with (a stale or partly filled table must not rank)
+    if (hdr->R != R || hdr->ngroups * K > nslots) return;
     if (g >= hdr->ngroups || y >= groups[g].ny) return;
     double s0 = 0.0, s1 = 0.0;
     for (int c = 0; c < nchunks; c++) {
@@ -406,6 +409,11 @@ extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, in
     const int nslots = ngroups * K;
     PclPoseRec* recs = (PclPoseRec*)workspace;
     float* partials = (float*)((char*)workspace + trim_align((size_t)nslots * sizeof(PclPoseRec)));
+    // every entry starts as NaN (0xFFFFFFFF): what the finish kernel does not write — `ngroups` below the table's group count,
+    // a blob built from another table — ranks last in the caller's selection instead of as whatever the buffer held
+    hipError_t me = hipMemsetAsync(loss_table, 0xFF, (size_t)K * R * sizeof(float), s);
+    if (me == hipSuccess && count_table) me = hipMemsetAsync(count_table, 0, (size_t)K * R * sizeof(float), s);
+    if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(pcl_trim_pose_setup_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, trans, rot, K, hdr, grs, ngroups, recs);
     PclTrimArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);

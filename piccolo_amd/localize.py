@@ -118,6 +118,8 @@ def read_image(filename):
 def _to_img(img8, dev):
     # host division, like the reference (localize.py:169); exactly k/255 by construction: tagged, so that packing it never waits
     # for the device-side exactness check
+    if img8.dtype != np.uint8:                    # the tag below promises levels k/255: only a decoded 8-bit image keeps it
+        raise TypeError("_to_img: expected a uint8 image, got %s" % img8.dtype)
     return synth.mark_levels((torch.from_numpy(img8).float() / 255.).to(dev))
 
 

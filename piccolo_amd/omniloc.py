@@ -172,10 +172,15 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
         # image (color_mod / match_color give each image its own rgb): the engine owns a private copy of the packed cloud whose
         # address the captured graph holds, and a cloud with other colours is copied into it (24 bytes per point on the device)
         # instead of capturing a new graph per image.
-        gd = _cached("gd", (xyz,), lambda: make(ops.Cloud.private_copy(cloud)), sub=(B, p0.H, p0.W, p0.fmt) + hyper)
-        if getattr(gd, "_cloud_src", None) is not cloud:
+        def make_private():
+            g = make(ops.Cloud.private_copy(cloud))
+            g._cloud_src = weakref.ref(cloud)                # the copy just made IS this cloud: nothing to copy on first use
+            return g
+        # (the fuse limit is read by pcl_gd_run per call but frozen into a captured graph: part of the key)
+        gd = _cached("gd", (xyz,), make_private, sub=(B, p0.H, p0.W, p0.fmt, os.environ.get("PCL_GD_FUSE_BLOCKS")) + hyper)
+        if gd._cloud_src() is not cloud:                     # weak: the engine must not keep packed clouds of past images alive
             gd.cloud.data.copy_(cloud.data)
-            gd._cloud_src = cloud
+            gd._cloud_src = weakref.ref(cloud)
         gd.box.copy_(ops._dev(box).reshape(6))              # in place: the captured graph holds this buffer's address
         gd.reset(trans, rot)
     if len(panos) > 1 or use_graph:

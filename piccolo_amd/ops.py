@@ -147,6 +147,9 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
     return out
 
 
+TRIM_MAX_ROT = 1024        # pcl_trim_groups: rotations per table (include/piccolo_hip.h)
+
+
 class TrimGroups:
     """Classes of equal (pitch, roll) of an (R, 3) rotation table, built on the device (pcl_trim_groups) — what trim_loss_table
     needs from the rotation grid.  Built once per grid: the group count is read back here (one 4-byte D2H copy), so that the

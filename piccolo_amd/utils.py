@@ -175,8 +175,16 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     K, Rn = len(trans), len(rot)
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img, many_poses=True)
     # the (pitch, roll) classes of the rotation table: once per table (the grid is cached per config in make_input)
-    groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot)) if torch.is_tensor(rot) else ops.TrimGroups(rot)
-    table = ops.trim_loss_table(cloud, pano, trans, groups).reshape(-1)          # row-major (K, R) like the reference's loss_table
+    if Rn <= ops.TRIM_MAX_ROT:
+        groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot)) if torch.is_tensor(rot) else ops.TrimGroups(rot)
+        table = ops.trim_loss_table(cloud, pano, trans, groups).reshape(-1)      # row-major (K, R) like the reference's loss_table
+    else:
+        # more rotations than the yaw-sharing launch classifies (its table of classes lives in LDS): the generic forward-only
+        # kernel over all pairs, a slice of translations at a time
+        tr, ro = ops._dev(trans).reshape(-1, 3), ops._dev(rot).reshape(-1, 3)
+        rows = max(1, 65536 // Rn)
+        table = torch.cat([ops.sampling_loss(cloud, pano, tr[k0:k0 + rows].repeat_interleave(Rn, 0), ro.repeat(min(rows, K - k0), 1),
+                                             with_grad=False)[:, 0] for k0 in range(0, K, rows)])
     num_input = min(num_input, K * Rn)
     # loss_table.argsort()[:num_input] (utils.py:500-501); topk is one selection kernel where argsort of a few thousand
     # values runs ~100 tiny merge-sort launches (1 ms per image); NaN losses (nothing sampled) rank last in both

@@ -780,6 +780,9 @@ def g21_full_size_batch_loss():
 
 
 # ----------------------------------------------------------------------------- G22
+G22B_ITERS = [0, 1, 2, 3, 4, 10, 50, 99]
+
+
 def g22_shipped_shape_end_to_end():
     """The reference's omniloc_batch, full 100 iterations, at the sizes of its SHIPPED config (configs/stanford_parallel.ini:
     1M points / sample_rate 6 = 166 667 points, 2048x1024 panorama, num_input 6, lr 0.1, patience 5, factor 0.8) on 4 scenes,
@@ -790,6 +793,9 @@ def g22_shipped_shape_end_to_end():
     N, H, W, S, B = 166_667, 1024, 2048, 4, 6
     cfg = Cfg(lr=0.1, num_iter=100, patience=5, factor=0.8, out_of_room_quantile=0.05, visualize=False, num_input=B)
     rows, sums = [], []
+    it_rec = {k: [] for k in ("fwd_trans", "fwd_rot", "fwd_loss", "adam_grad", "adam_lr", "adam_param_after", "loss_f64", "grad_t_f64", "grad_ypr_f64",
+                               "perm_fwd_trans", "perm_fwd_rot", "perm_fwd_loss")}
+    fin_p, fin_l = ([], []), ([], [])
     for s in range(S):
         seed = 700 + s
         xyz, rgb = synth.box_room(N, seed=seed)
@@ -801,16 +807,115 @@ def g22_shipped_shape_end_to_end():
         R_gt = synth.rot_from_ypr_np(ypr_gt)
         perm = np.random.default_rng(2000 + s).permutation(N)
         out = []
-        for x, c in ((xyz, rgb), (xyz[perm], rgb[perm])):
-            r = ref_omniloc.omniloc_batch(torch.from_numpy(img), torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(trans.copy()),
-                                          torch.from_numpy(rot.copy()), cfg, {})
+        for run, (x, c) in enumerate(((xyz, rgb), (xyz[perm], rgb[perm]))):
+            rec = Recorder()                     # G22b: every forward, gradient and optimiser step of the run (as G5)
+            rec.install()
+            try:
+                r = ref_omniloc.omniloc_batch(torch.from_numpy(img), torch.from_numpy(x), torch.from_numpy(c), torch.from_numpy(trans.copy()),
+                                              torch.from_numpy(rot.copy()), cfg, {})
+            finally:
+                rec.remove()
             t, R = r[0].detach().numpy().reshape(3), r[1].detach().numpy()
             out.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
+            a = rec.arrays("")
+            # all six candidates at the end: the post-step, pre-clamp parameters the function picks its return value from
+            # (omniloc.py:260-263,271-277; Adam's order [t, yaw, roll, pitch]) and the losses of the last forward
+            fin_p[run].append(a["adam_param_after"][-1])
+            fin_l[run].append(a["fwd_loss"][-1])
+            if run == 1:                         # the reference's own rerun (points permuted), same iterations: the yardstick of
+                for k in ("fwd_trans", "fwd_rot", "fwd_loss"):         # every free-running comparison
+                    it_rec["perm_" + k].append(a[k][G22B_ITERS])
+            if run == 0:
+                for k in ("fwd_trans", "fwd_rot", "fwd_loss", "adam_grad", "adam_lr", "adam_param_after"):
+                    it_rec[k].append(a[k][G22B_ITERS])
+                # the reference's own fp64 evaluation AT THE RECORDED fp32 POSES of those iterations: the yardstick of every
+                # per-evaluation comparison (its fp32 run's distance from it)
+                l64, gt64, gy64 = [], [], []
+                for k in G22B_ITERS:
+                    l, gt, gy = loss_and_grads(x, c, img, a["fwd_trans"][k].astype(np.float64), a["fwd_rot"][k].astype(np.float64), torch.float64)
+                    l64.append(l); gt64.append(gt); gy64.append(gy)
+                it_rec["loss_f64"].append(np.stack(l64)); it_rec["grad_t_f64"].append(np.stack(gt64)); it_rec["grad_ypr_f64"].append(np.stack(gy64))
         rows.append(np.stack(out))
         print("G22 seed %d t_err %.4f / %.4f (perm)  r_err %.3f / %.3f  loss %.5f / %.5f" % (
             seed, rows[-1][0, 13], rows[-1][1, 13], rows[-1][0, 14], rows[-1][1, 14], rows[-1][0, 12], rows[-1][1, 12]), flush=True)
     # columns: t(3) R(9) loss t_err r_err ; axis 1: original / permuted point order
     save("g22_shipped_shape.npz", N=N, H=H, W=W, B=B, seed0=700, batch=np.stack(rows), img_sum=np.array(sums))
+    # G22b: per scene, iterations G22B_ITERS of the original-order run: forward poses (S, 8, 6, 3), loss_list (S, 8, 6), autograd
+    # gradients in Adam's order [t, yaw, roll, pitch] (S, 8, 6, 6), lr, post-step parameters; the reference's fp64 loss / gradients
+    # at those poses; and all six final candidates of both runs
+    save("g22b_shipped_iterations.npz", iters=np.array(G22B_ITERS), **{k: np.stack(v) for k, v in it_rec.items()},
+         final_param=np.stack([np.stack(fin_p[0]), np.stack(fin_p[1])], 1), final_loss=np.stack([np.stack(fin_l[0]), np.stack(fin_l[1])], 1))
+
+
+# ----------------------------------------------------------------------------- G23
+def g23_make_input_composed():
+    """The reference's make_input (utils.py:591-629) COMPOSED, for its three shipped configs: candidate grid -> trim_input_loss
+    (loss table, argsort, the `// len(rot)` / `% len(rot)` decode at utils.py:504-505) -> trim_input_hist_secondary -> final
+    starting poses.  The configs go through the reference's own parse_ini and localize.get_init_dict (localize.py:18-73; the
+    module imports with a stub for tensorboard).  Intermediates are READ OUT OF THE RUNNING FUNCTIONS: a profile hook copies the
+    locals of trim_input_loss / trim_input_hist_secondary (loss_table, min_inds, hist_intersect, their arguments) at their return.
+    Scene: 30 000-point room, 64x128 panorama with a black patch; the cloud is subsampled by the config's sample_rate the way
+    data_utils.read_stanford does it at load time (stanford_parallel.ini: 6)."""
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    if not hasattr(torch.utils, "tensorboard"):
+        torch.utils.tensorboard = tb
+    import localize as ref_localize
+    xyz0, rgb0, img, t_gt, ypr_gt = small_scene(n=30000, H=64, W=128, seed=23, black_patch=True)
+    out = dict(xyz=xyz0, rgb=rgb0, img=img, t_gt=t_gt, ypr_gt=ypr_gt)
+    codes = {ref_utils.trim_input_loss.__code__: ("loss", ("loss_table", "min_inds", "trans", "rot", "trimmed_trans", "trimmed_rot")),
+             ref_utils.trim_input_hist_secondary.__code__: ("hist", ("hist_intersect", "min_inds", "trans", "rot"))}
+    for name in ("stanford.ini", "stanford_parallel.ini", "omniscenes.ini"):
+        cfg = ref_parse.parse_ini(os.path.join(REF, "configs", name))
+        init_dict = ref_localize.get_init_dict(cfg)
+        rate = getattr(cfg, "sample_rate", 1)
+        xyz, rgb = xyz0, rgb0
+        if rate > 1:                                           # data_utils.py:36-41: every sample_rate-th point, int(N / rate) of them
+            k = int(xyz0.shape[0] / rate)
+            xyz, rgb = xyz0[::rate][:k], rgb0[::rate][:k]
+        got = {}
+
+        def hook(frame, event, arg):
+            if event == "return" and frame.f_code in codes:
+                tag, names = codes[frame.f_code]
+                for nm in names:
+                    got[tag + "_" + nm] = frame.f_locals[nm].detach().clone().numpy()
+
+        torch.manual_seed(0)
+        sys.setprofile(hook)
+        try:
+            it, ir = ref_utils.make_input(torch.from_numpy(img), torch.from_numpy(xyz), torch.from_numpy(rgb), cfg.num_input, init_dict,
+                                          cfg.criterion, cfg.num_intermediate)
+        finally:
+            sys.setprofile(None)
+        # the reference against ITSELF: the second stage again on the same survivors with the points in another order.  Its
+        # render is set-valued (duplicate indices in index_put_, argsort ties), so its own scores move — the yardstick for
+        # every comparison of histogram scores
+        first = dict(got)
+        perm = np.random.default_rng(23).permutation(len(xyz))
+        sys.setprofile(hook)
+        try:
+            ref_utils.trim_input_hist_secondary(torch.from_numpy(img), torch.from_numpy(xyz[perm]), torch.from_numpy(rgb[perm]),
+                                                torch.from_numpy(first["hist_trans"]), torch.from_numpy(first["hist_rot"]), cfg.num_input,
+                                                init_dict["num_split_h"], init_dict["num_split_w"])
+        finally:
+            sys.setprofile(None)
+        perm_scores = got["hist_hist_intersect"]
+        got = first
+        got["hist_hist_intersect_permuted"] = perm_scores
+        print("    the reference's scores move by %.2e when its points are permuted" % np.abs(perm_scores - got["hist_hist_intersect"]).max())
+        tag = name.replace(".ini", "")
+        out[tag + "_init_dict"] = json.dumps(init_dict)
+        out[tag + "_num"] = np.array([cfg.num_input, cfg.num_intermediate, rate, len(xyz)])
+        for k, v in got.items():
+            out[tag + "_" + k] = v
+        out[tag + "_input_trans"], out[tag + "_input_rot"] = it.numpy(), ir.numpy()
+        tbl = np.sort(got["loss_loss_table"].reshape(-1))
+        print("G23", name, "grid", got["loss_loss_table"].shape, "table gap at the cut %.3e (table %.3f..%.3f)" % (
+            tbl[cfg.num_intermediate] - tbl[cfg.num_intermediate - 1], tbl[0], tbl[-1]),
+            "hist scores %.4f..%.4f" % (got["hist_hist_intersect"].min(), got["hist_hist_intersect"].max()), flush=True)
+    save("g23_make_input.npz", **out)
 
 
 if __name__ == "__main__":
@@ -818,7 +923,7 @@ if __name__ == "__main__":
     todo = [g1_cloud2idx, g2_sample_from_img, g3_g4_loss_grad, g5_trajectories, g6_quantile, g7_trim_input_loss,
             g8_make_pano, g9_parse, g10_candidates, g11_end_to_end, g12_trim_input_hist, g13_color_match, g14_color_mod, g15_data_utils, g16_histogram, g17_small_utils,
             g18_end_to_end_many_seeds, g19_trim_hist_empty_blocks,
-            g20_standalone_backward, g21_full_size_batch_loss, g22_shipped_shape_end_to_end]
+            g20_standalone_backward, g21_full_size_batch_loss, g22_shipped_shape_end_to_end, g23_make_input_composed]
     for fn in todo:
         if only and not any(fn.__name__.startswith(o) for o in only):
             continue

@@ -39,3 +39,38 @@ def _check_vs_oracle(parity, out, r64, r32, n, tag=""):
     gap_t, gap_r = rel(r32["grad_t"], r64["grad_t"]), rel(r32["grad_ypr"], r64["grad_ypr"])
     parity(tag + "grad_t vs fp64", rel(out[:, 2:5], r64["grad_t"]), 2 * gap_t + 5e-6 + 20.0 * dcount / n, gap_t)
     parity(tag + "grad_ypr vs fp64", rel(out[:, 5:8], r64["grad_ypr"]), 2 * gap_r + 5e-6 + 20.0 * dcount / n, gap_r)
+
+
+def check_selection(got_idx, ref_values, n, tol, largest=False):
+    """A top-n selection against the reference's values, as far as those values can decide it.  Every value is known to +-tol
+    (a scalar, or one tolerance per entry: e.g. 10 x the table tolerance, plus the measured difference where a mask flip moved
+    an entry).  An entry MUST be selected when fewer than n others can possibly rank ahead of it, MAY be selected only when
+    fewer than n others certainly rank ahead of it, and where its rank is certain (as many certainly ahead as possibly ahead)
+    it must hold exactly that RANK in the selection.  -> (number of must-haves, number of rank-checked positions)."""
+    v = np.asarray(ref_values, np.float64).reshape(-1)
+    v = -v if largest else v
+    tol = np.broadcast_to(np.asarray(tol, np.float64).reshape(-1), v.shape)
+    lo, hi = v - tol, v + tol
+    got = [int(i) for i in np.asarray(got_idx).reshape(-1)]
+    assert len(got) == n == len(set(got)), (len(got), n)
+    possibly_ahead = (lo[None, :] < hi[:, None]).sum(1) - 1          # j != i with lo_j < hi_i (i itself always counts once)
+    certainly_ahead = (hi[None, :] < lo[:, None]).sum(1)
+    must = {int(i) for i in np.nonzero(possibly_ahead < n)[0]}
+    may = {int(i) for i in np.nonzero(certainly_ahead < n)[0]}
+    assert must <= set(got), ("selection misses", sorted(must - set(got)))
+    assert set(got) <= may, ("selection includes", sorted(set(got) - may))
+    ranked = 0
+    for i in must:
+        if possibly_ahead[i] == certainly_ahead[i]:                  # the reference's rank of i is unambiguous at this tolerance
+            assert got[int(certainly_ahead[i])] == i, ("rank", int(certainly_ahead[i]), got[int(certainly_ahead[i])], i)
+            ranked += 1
+    return len(must), ranked
+
+
+def match_rows(rows, table, atol=1e-6):
+    """index in `table` of every row of `rows` (each must match exactly one)"""
+    rows, table = np.asarray(rows, np.float64), np.asarray(table, np.float64)
+    d = np.abs(rows[:, None, :] - table[None, :, :]).max(-1)
+    idx = d.argmin(1)
+    assert (d[np.arange(len(rows)), idx] <= atol).all() and ((d <= atol).sum(1) == 1).all()
+    return idx

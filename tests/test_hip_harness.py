@@ -206,6 +206,61 @@ def test_omniloc_all_equals_sequential_calls():
     assert torch.equal(t_all, t_seq) and torch.equal(r_all, r_seq)      # the callers' rows end up identical too
 
 
+def test_make_input_composed_matches_the_reference(oracle, parity):
+    """G23: the reference's make_input (utils.py:591-629) run on one scene for its three shipped configs, intermediates read out
+    of the running functions.  Stage by stage on the reference's own candidate tables — the loss table of the yaw-shared trim
+    launch, the survivors through the `// len(rot)`, `% len(rot)` decode (utils.py:500-505), the histogram scores of those
+    survivors, the final starting poses — and then the product's make_input from nothing but the image, the cloud and the
+    init_dict: its own candidate grids must be the reference's, and its final poses the reference's as far as the reference's
+    scores decide them (its own rerun with permuted points moves them by 0.4e-2 ... 2e-2)."""
+    from oracle import hist
+    from parity_helpers import check_selection, match_rows
+    from piccolo_amd import ops, utils
+    from test_oracle_golden import G23_CONFIGS, g23_case, g23_check_table
+    g = load_golden("g23_make_input.npz")
+    dev = torch.device("cuda")
+    for tag in G23_CONFIGS:
+        xyz, rgb, img, init, n_in, n_mid, d = g23_case(g, tag)
+        X, C, I = [torch.from_numpy(a).to(dev) for a in (xyz, rgb, img)]
+        K, Rn = d["loss_loss_table"].shape
+        tr, ro = torch.from_numpy(d["loss_trans"]).to(dev), torch.from_numpy(d["loss_rot"]).to(dev)
+        # stage 1 on the reference's tables (its rotation order is that of a Python set of strings: arbitrary per process)
+        table = ops.trim_loss_table(ops.Cloud(X, C), ops.Pano(I, fmt="u8"), tr, ops.TrimGroups(ro)).cpu().numpy()
+        t1, r1 = utils.trim_input_loss(I, X, C, tr, ro, n_mid)
+        got = match_rows(t1.cpu().numpy(), d["loss_trans"]) * Rn + match_rows(r1.cpu().numpy(), d["loss_rot"])
+        assert np.array_equal(np.sort(table.reshape(-1)[got]), np.sort(table.reshape(-1))[:n_mid])      # it returns its own table's best
+        g23_check_table(parity, "device", tag, table, d["loss_loss_table"], len(xyz), n_mid, got=got)
+        # stage 2 on the reference's survivors
+        ht, hr = torch.from_numpy(d["hist_trans"]).to(dev), torch.from_numpy(d["hist_rot"]).to(dev)
+        scores = ops.hist_trim_scores(I, ops.Cloud(X, C), ht, hr, init["num_split_h"], init["num_split_w"]).cpu().numpy()
+        self_noise = np.abs(d["hist_hist_intersect_permuted"] - d["hist_hist_intersect"]).max()
+        parity("G23 %s: device histogram scores vs the reference's (yardstick: the reference's own rerun)" % tag,
+               np.abs(scores - d["hist_hist_intersect"]).max(), 2.5 * self_noise + 1e-3, self_noise)
+        oscores, _ = hist.hist_scores(img, xyz, rgb, d["hist_trans"], d["hist_rot"], init["num_split_h"], init["num_split_w"])
+        parity("G23 %s: device histogram scores vs the oracle's (same nearest-wins render)" % tag, np.abs(scores - oscores).max(), 2e-3)
+        ft, fr = utils.trim_input_hist_secondary(I, X, C, ht, hr, n_in, init["num_split_h"], init["num_split_w"])
+        sel = match_rows(np.concatenate([ft.cpu().numpy(), fr.cpu().numpy()], 1), np.concatenate([d["hist_trans"], d["hist_rot"]], 1))
+        check_selection(sel, d["hist_hist_intersect"], n_in, np.abs(scores - d["hist_hist_intersect"]) + 1e-6, largest=True)
+        # the composition from scratch: own grids, own trims
+        utils._ROT_GRIDS.clear()
+        it, ir = utils.make_input(I, X, C, n_in, init, "loss_histogram", n_mid)
+        own_t = utils.generate_trans_points(X, init, device=dev).cpu().numpy()
+        own_r = utils.generate_rot_points(init, device=dev).cpu().numpy()
+        assert own_t.shape == d["loss_trans"].shape and np.abs(own_t - d["loss_trans"]).max() <= 1e-5          # same grid, same order
+        assert own_r.shape == d["loss_rot"].shape
+        match_rows(own_r, d["loss_rot"], atol=1e-5)                                                          # same rotations, as a set
+        fin = np.concatenate([it.cpu().numpy(), ir.cpu().numpy()], 1)
+        assert fin.shape == (n_in, 6)
+        # every final pose is one of the reference's stage-1 survivors or ranks within the stage-1 tie band, and as a selection
+        # among the reference's survivors it is admissible at the measured score tolerance
+        pool = np.concatenate([d["hist_trans"], d["hist_rot"]], 1)
+        dist = np.abs(fin[:, None, :] - pool[None, :, :]).max(-1)
+        inside = dist.min(1) <= 1e-5
+        parity("G23 %s: make_input from scratch, final poses outside the reference's 50 survivors (stage-1 ties)" % tag, (~inside).sum(), 1)
+        if inside.all():
+            check_selection(dist.argmin(1), d["hist_hist_intersect"], n_in, np.abs(scores - d["hist_hist_intersect"]) + 1e-6, largest=True)
+
+
 def _run_bench(cmd, env_extra, timeout=900):
     import json as js
     import os

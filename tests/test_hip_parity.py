@@ -267,6 +267,22 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
     want = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()
     groups.ngroups = 24
     assert np.array_equal(ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy(), want)
+    # a group count BELOW the table's, or a groups blob of another rotation table: the launch cannot fill the table, and what it
+    # does not compute must rank last (NaN), never as whatever the buffer held
+    groups.ngroups = 2
+    assert np.isnan(ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()).all()
+    other = ops.TrimGroups(T(yaw_only))                         # 8 yaws: 2 groups, header says R = 8
+    other.rot, other.R = T(stanford), 24
+    assert np.isnan(ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), other).cpu().numpy()).all()
+    # more rotations than pcl_trim_groups classifies (R > 1024): utils.trim_input_loss falls back to the generic forward kernel
+    many = rng.uniform(-3.0, 3.0, size=(ops.TRIM_MAX_ROT + 6, 3)).astype(np.float32)
+    with pytest.raises(Exception):
+        ops.TrimGroups(T(many))
+    small = ops.Cloud(X[:5000].contiguous(), C[:5000].contiguous())
+    tt2, rr2 = utils.trim_input_loss(img, X[:5000].contiguous(), C[:5000].contiguous(), T(trans[:3]), T(many), 9)
+    gen = ops.sampling_loss(small, ops.Pano(img, fmt="u8"), T(np.repeat(trans[:3], len(many), 0)), T(np.tile(many, (3, 1))), with_grad=False)[:, 0].cpu().numpy()
+    best = np.argsort(gen, kind="stable")[:9]
+    assert np.array_equal(tt2.cpu().numpy(), trans[:3][best // len(many)]) and np.array_equal(rr2.cpu().numpy(), many[best % len(many)])
     # G7: the reference's own loss table
     g = load_golden("g7_trim_input_loss.npz")
     tab = ops.trim_loss_table(ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]), fmt="u8"), T(g["trans"]), ops.TrimGroups(T(g["rot"]))).cpu().numpy()
@@ -851,6 +867,52 @@ def test_shipped_shape_end_to_end_as_close_to_the_reference_as_it_is_to_itself(o
             po._cache.clear()
         assert all(torch.equal(a, b) for a, b in zip(r, r2)), s
     g22_compare(np.array(rows), g["batch"], parity)
+
+
+def test_fused_iteration_at_the_shipped_shape_per_evaluation(ops, oracle, parity):
+    """G22b: the reference's omniloc_batch at its shipped shape (166 667 points, 2048x1024, 6 candidates: ONE launch per GD
+    iteration here, pcl_loss_fused_kernel) pinned PER EVALUATION (omniloc.py:249-269, 311-356): the reference's forward poses,
+    loss_list and autograd gradients of iterations 0-4, 10, 50, 99 of four scenes, its own fp64 evaluation at those poses, its
+    permuted-order rerun, and all six final candidates of both runs.
+      (i)   free-running through the fused kernel: iteration 0's loss_list, iteration 1's pose wherever the reference's gradient
+            sign is certain, then loss and pose of the candidates whose six signs are (see g22b_free_running for why G5's 1e-4
+            over three iterations is not available at this shape: the reference's own fp32 gradient is 1 % off);
+      (ii)  teacher-forced: ops.sampling_loss at the reference's recorded poses of all eight iterations, within 2 x the
+            reference's own fp32 distance from its fp64 values — the same kernel arithmetic the fused launch runs;
+      (iii) all six final candidates against the reference's, per candidate, with the reference's own rerun as the yardstick."""
+    import ctypes
+    from piccolo_amd import _lib
+    from test_oracle_golden import g22_scene, g22b_final_candidates, g22b_free_running, g22b_teacher_forced
+    g, gb = load_golden("g22_shipped_shape.npz"), load_golden("g22b_shipped_iterations.npz")
+    B, S = int(g["B"]), g["batch"].shape[0]
+    fz = ctypes.c_int(-1)
+    assert _lib.load().pcl_gd_plan(int(g["N"]), B, None, None, ctypes.byref(fz)) == 0 and fz.value == 1     # the fused path
+    fin_p, fin_l, worst = [], [], np.zeros(3)
+    for s in range(S):
+        xyz, rgb, img, trans, rot, t_gt, R_gt = g22_scene(oracle, g, s)
+        cloud, pano = ops.Cloud(T(xyz), T(rgb)), ops.Pano(T(img))
+        box = ops.quantile_box(T(xyz), 0.05)
+        gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
+        fwd, hist = {}, None
+        for n_it in (1, 2, 3):
+            gd.reset(T(trans), T(rot))
+            hist = gd.run(n_it, history=True).cpu().numpy()
+            fwd[n_it] = gd.result().cpu().numpy()[:, :6]
+        g22b_free_running(parity, "fused kernel", hist, fwd, gb, s)
+
+        def ev(t, r):
+            o = ops.sampling_loss(cloud, pano, T(t), T(r), with_grad=True).cpu().numpy()
+            return o[:, 0], o[:, 2:5], o[:, 5:8]
+
+        worst = np.maximum(worst, g22b_teacher_forced(parity, "loss kernel", ev, gb, s))
+        gd.reset(T(trans), T(rot))
+        gd.run(100)
+        res = gd.result().cpu().numpy()
+        # batch mode: the forward copy is the post-step, pre-clamp parameter set the reference returns from (omniloc.py:260-263)
+        fin_p.append(np.concatenate([res[:, :3], res[:, [3, 5, 4]]], 1))           # Adam's order [t, yaw, roll, pitch] like the fixture
+        fin_l.append(res[:, 12])
+    parity("G22b: loss kernel at the recorded poses, worst error / the reference's own fp32 error (loss, grad_t, grad_ypr)", worst.max(), 2.0)
+    g22b_final_candidates(parity, "fused kernel", np.stack(fin_p), np.stack(fin_l), gb)
 
 
 def test_cloud_order_is_a_morton_sorted_permutation(ops):
