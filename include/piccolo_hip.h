@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 5 /* 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
+#define PCL_ABI_VERSION 6 /* 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -153,6 +153,16 @@ int pcl_gd_plan(int64_t n, int B, int *nchunks_host, int *poses_per_block_host, 
  * launch share each cloud chunk in L2 and amortise the per-block costs: at cfg 2, 4 images x 32 candidates per launch
  * run at the efficiency of cfg 3. */
 int pcl_gd_set_panos(void *state, const uint64_t *panos, int B, void *stream);
+/* The same from a short HOST list: candidates [i * per_image, (i + 1) * per_image) sample panos_host[i] (device addresses of
+ * packed panoramas; B = nimages * per_image).  The addresses travel as kernel arguments — nothing is copied to the device, so
+ * nothing waits for the work the stream already holds (one launch per 64 images). */
+int pcl_gd_set_pano_groups(void *state, const uint64_t *panos_host, int nimages, int per_image, void *stream);
+/* The end of omniloc_batch, omniloc.py:271-277, for nimages x per_image candidates (B = nimages * per_image): per image the
+ * candidate whose LAST forward had the smallest loss (torch.argmin semantics: first of equal minima, a NaN loss wins), as
+ * winners [nimages][16] = post-step translation (3), R = RZ(yaw) RY(pitch) RX(roll) of the post-step angles (9, row-major),
+ * that loss, yaw / pitch / roll.  leaf_trans / leaf_rot [B][3] (nullable) receive every candidate's leaf parameters — what the
+ * reference leaves in the caller's input_trans / input_rot, whose rows it optimises in place (omniloc.py:216-219). */
+int pcl_gd_winner(const void *state, int nimages, int per_image, float *winners, float *leaf_trans, float *leaf_rot, void *stream);
 
 /* ---- kernel timer (measurement aid, HOST object) --------------------------------------------------------------
  * A pool of hipEvent pairs.  When a timer is passed to pcl_gd_run, every launch of the fused loss+gradient kernel is
@@ -237,6 +247,17 @@ int pcl_hist_trim_reduce(const float *inter, const int32_t *nproj, const int32_t
  *     built from a table of another size, or holds more groups than `ngroups`, NOTHING is written over them: an entry the
  *     launch did not compute ranks last in the caller's selection (NaN), never as stale memory. */
 size_t pcl_trim_groups_bytes(int R);
+/* The two selections of the initialisation stage in one launch each (one block per problem, nprob problems of M values):
+ *   largest == 0, rot_per_trans == len(rot):  utils.py:500-505  min_inds = loss_table.flatten().argsort()[:n_keep];
+ *                                             out_trans = trans[min_inds // len(rot)], out_rot = rot[min_inds % len(rot)]
+ *   largest == 1, rot_per_trans == 0:         utils.py:583-586  min_inds = flip(hist_intersect.argsort()[-n_keep:]);
+ *                                             out_trans = trans[min_inds], out_rot = rot[min_inds]
+ * values [nprob][M]; problem p reads its pose rows from trans / rot + p * pose_stride * 3 floats (pose_stride 0: shared tables);
+ * out_trans / out_rot [nprob][n_keep][3], out_idx [nprob][n_keep] (nullable).  Exact and deterministic: ascending by value with
+ * ties by ascending index (a stable argsort); largest: descending, ties by descending index (the flipped tail of that argsort);
+ * NaN ranks last in both.  n_keep <= min(M, 1024). */
+int pcl_select_poses(const float *values, int nprob, int M, int n_keep, int largest, const float *trans, const float *rot,
+                     int rot_per_trans, int64_t pose_stride, float *out_trans, float *out_rot, int *out_idx, void *stream);
 int pcl_trim_groups(const float *rot, int R, void *groups, void *stream);
 size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups);
 int pcl_trim_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans, int K,

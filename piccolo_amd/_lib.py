@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
@@ -74,6 +74,9 @@ SIGNATURES = {
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
     "pcl_gd_plan": (_int, [_i64, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
+    "pcl_gd_set_pano_groups": (_int, [_vp, _c.POINTER(_c.c_uint64), _int, _int, _vp]),
+    "pcl_gd_winner": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "pcl_select_poses": (_int, [_vp, _int, _int, _int, _int, _vp, _vp, _int, _i64, _vp, _vp, _vp, _vp]),
     "pcl_cloud2idx": (_int, [_vp, _i64, _vp, _vp]),
     "pcl_sample_from_img": (_int, [_vp, _int, _int, _int, _vp, _i64, _vp, _vp]),
     "pcl_cloud2idx_backward": (_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -9,6 +9,8 @@
 
 #include "pcl_gd_device.h"
 
+#define PCL_GD_MAX_IMAGES 64     // panorama addresses per pcl_gd_set_pano_groups launch (they travel as kernel arguments)
+
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
                     int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse);
 size_t pcl_partials_bytes(int64_t n, int B);
@@ -362,6 +364,77 @@ extern "C" int pcl_gd_set_panos(void* state, const uint64_t* panos, int B, void*
     if (!state || B <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_set_panos_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_recs(state, B),
                        gd_recs(state, B, 1), (const unsigned long long*)panos, B);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+// The panorama of every candidate from a SHORT host list: image i's address for candidates [i * per_image, (i + 1) * per_image).
+// The addresses travel as kernel arguments — no device table, so no host-to-device copy in front of a refinement (a pageable
+// H2D copy waits for everything the stream holds: it cost the shipped-shape pipeline its overlap of host and device work).
+struct PclPanoList { unsigned long long p[PCL_GD_MAX_IMAGES]; };
+
+__global__ void pcl_gd_set_pano_groups_kernel(PclPoseRec* recs, PclPoseRec* recs_shadow, PclPanoList list, int b0, int count, int per_image)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const unsigned long long p = list.p[j / per_image];
+    const int b = b0 + j;
+    recs[b].pano_lo = recs_shadow[b].pano_lo = (uint32_t)(p & 0xffffffffull);
+    recs[b].pano_hi = recs_shadow[b].pano_hi = (uint32_t)(p >> 32);
+}
+
+extern "C" int pcl_gd_set_pano_groups(void* state, const uint64_t* panos_host, int nimages, int per_image, void* stream)
+{
+    if (!state || !panos_host || nimages <= 0 || per_image <= 0 || (int64_t)nimages * per_image > 0x7fffffff) return PCL_EINVAL;
+    const int B = nimages * per_image;
+    for (int i0 = 0; i0 < nimages; i0 += PCL_GD_MAX_IMAGES) {
+        PclPanoList list;
+        const int m = nimages - i0 < PCL_GD_MAX_IMAGES ? nimages - i0 : PCL_GD_MAX_IMAGES;
+        for (int i = 0; i < PCL_GD_MAX_IMAGES; i++) list.p[i] = i < m ? (unsigned long long)panos_host[i0 + i] : 0ull;
+        const int count = m * per_image;
+        hipLaunchKernelGGL(pcl_gd_set_pano_groups_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_recs(state, B),
+                           gd_recs(state, B, 1), list, i0 * per_image, count, per_image);
+        PCL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// The end of omniloc_batch (omniloc.py:271-277) for `nimages` images of `per_image` candidates each: the candidate whose LAST
+// forward had the smallest loss (torch.argmin: the first of equal minima, and a NaN loss counts as the minimum), its post-step
+// translation, R = RZ RY RX of its post-step angles, that loss and the angles: 16 floats per image.  Also hands the leaf
+// parameters of all candidates back (the reference optimises views of the caller's tensors in place, omniloc.py:216-219).
+__global__ void pcl_gd_winner_kernel(const PclGdPose* __restrict__ st, int nimages, int per_image, float* __restrict__ out,
+                                     float* __restrict__ leaf_trans, float* __restrict__ leaf_rot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nimages) return;
+    const PclGdPose* s = st + (int64_t)i * per_image;
+    int k = 0;
+    float best = s[0].last_loss;
+    for (int b = 1; b < per_image && best == best; b++) {
+        const float l = s[b].last_loss;
+        if (l != l || l < best) { best = l; k = b; }
+    }
+    float* o = out + (int64_t)i * 16;
+    float R[9];
+    pcl_rot_from_ypr(s[k].fwd[3], s[k].fwd[4], s[k].fwd[5], R);
+    for (int q = 0; q < 3; q++) { o[q] = s[k].fwd[q]; o[13 + q] = s[k].fwd[3 + q]; }
+    for (int q = 0; q < 9; q++) o[3 + q] = R[q];
+    o[12] = s[k].last_loss;
+    for (int b = 0; b < per_image; b++) {
+        const int64_t row = ((int64_t)i * per_image + b) * 3;
+        for (int q = 0; q < 3; q++) {
+            if (leaf_trans) leaf_trans[row + q] = s[b].leaf[q];
+            if (leaf_rot) leaf_rot[row + q] = s[b].leaf[3 + q];
+        }
+    }
+}
+
+extern "C" int pcl_gd_winner(const void* state, int nimages, int per_image, float* winners, float* leaf_trans, float* leaf_rot, void* stream)
+{
+    if (!state || !winners || nimages <= 0 || per_image <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_gd_winner_kernel, dim3((nimages + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const PclGdPose*)state, nimages,
+                       per_image, winners, leaf_trans, leaf_rot);
     PCL_LAUNCH_CHECK();
     return 0;
 }

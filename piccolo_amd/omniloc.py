@@ -145,7 +145,8 @@ GRAPH_POINT_POSES = 4_000_000          # use graph replay when points x candidat
 
 
 def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
-    """Run the on-device GD for the rows of trans / rot (candidate b samples panos[b]) and return gd.result().
+    """Run the on-device GD for the rows of trans / rot and return the GradientDescent object (read gd.result() / gd.winner()).
+    `panos`: one packed panorama per query image; the B rows split evenly over them, image by image.
     The GradientDescent object (state, workspace, captured graph) is cached per cloud and launch shape."""
     cloud = packed_cloud(xyz, rgb)
     trans, rot = ops._dev(trans).reshape(-1, 3), ops._dev(rot).reshape(-1, 3)
@@ -162,8 +163,8 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
         use_graph = cloud.n * B <= GRAPH_POINT_POSES
     use_graph = bool(use_graph) and vis_hook is None and not depth
 
-    def make(c=cloud):
-        return ops.GradientDescent(c, p0, trans, rot, box, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
+    def make(c=cloud, bx=box):
+        return ops.GradientDescent(c, p0, trans, rot, bx, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
                                    depth_mask=hyper[4], depth_tau=hyper[5])
     if not use_graph:
         gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
@@ -173,25 +174,47 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
         # address the captured graph holds, and a cloud with other colours is copied into it (24 bytes per point on the device)
         # instead of capturing a new graph per image.
         def make_private():
-            g = make(ops.Cloud.private_copy(cloud))
+            g = make(ops.Cloud.private_copy(cloud), ops._dev(box).reshape(6).clone())     # (its own box buffer: updated in place below)
             g._cloud_src = weakref.ref(cloud)                # the copy just made IS this cloud: nothing to copy on first use
+            g._box_src, g._fresh = box, True
             return g
         # (the fuse limit is read by pcl_gd_run per call but frozen into a captured graph: part of the key)
         gd = _cached("gd", (xyz,), make_private, sub=(B, p0.H, p0.W, p0.fmt, os.environ.get("PCL_GD_FUSE_BLOCKS")) + hyper)
+        fresh, gd._fresh = gd._fresh, False                  # (a new engine was initialised with these very poses)
         if gd._cloud_src() is not cloud:                     # weak: the engine must not keep packed clouds of past images alive
             gd.cloud.data.copy_(cloud.data)
             gd._cloud_src = weakref.ref(cloud)
-        gd.box.copy_(ops._dev(box).reshape(6))              # in place: the captured graph holds this buffer's address
-        gd.reset(trans, rot)
+        if gd._box_src is not box:                           # in place: the captured graph holds this buffer's address
+            gd.box.copy_(ops._dev(box).reshape(6))
+            gd._box_src = box                                # (the cached box tensor of this cloud: identity is enough)
+        if not fresh:
+            gd.reset(trans, rot)
     if len(panos) > 1 or use_graph:
-        gd.set_panos(list(panos) if len(panos) == B else [p0] * B)
+        gd.set_pano_groups(list(panos))                      # addresses as kernel arguments: no H2D copy, nothing waits
     if vis_hook is not None:
         vis_hook(gd, num_iter)
     elif use_graph:
         gd.run_graph(num_iter)
     else:
         gd.run(num_iter)
-    return gd.result()
+    return gd
+
+
+def _leaf_buffers(input_trans, input_rot, B):
+    """The caller's starting-pose tensors as write-back targets of pcl_gd_winner when they are contiguous float32 GPU tensors of B
+    rows (the harness's are); else fresh buffers plus a copy afterwards.  -> (buf_t, buf_r, after)"""
+    def usable(t):
+        return torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 3 * B and not t.requires_grad
+    bt = input_trans if usable(input_trans) else torch.empty(B, 3, dtype=torch.float32, device=ops.device())
+    br = input_rot if usable(input_rot) else torch.empty(B, 3, dtype=torch.float32, device=ops.device())
+
+    def after():
+        with torch.no_grad():
+            if bt is not input_trans:
+                input_trans.copy_(bt.reshape(input_trans.shape).to(input_trans.device))
+            if br is not input_rot:
+                input_rot.copy_(br.reshape(input_rot.shape).to(input_rot.device))
+    return bt, br, after
 
 
 def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_summaries):
@@ -209,7 +232,7 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     box = quantile_box_of(xyz, out_quantile)
     frames = []
     hook = (lambda gd, n: frames.extend(_run_with_frames(gd, img, xyz, rgb, n))) if vis else None
-    res = _refine(xyz, rgb, [pano], input_trans[starting_point], input_rot[starting_point], box, cfg, False, vis_hook=hook)[0]
+    res = _refine(xyz, rgb, [pano], input_trans[starting_point], input_rot[starting_point], box, cfg, False, vis_hook=hook).result()[0]
     R = _rot_matrix(res[3:6])
     out = torch.cat([res[0:3], R.reshape(-1), res[12:13]]).cpu()
     with torch.no_grad():
@@ -253,7 +276,7 @@ def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=Non
     Every starting point keeps omniloc's SEQUENTIAL semantics (its own Adam / scheduler, clamp applied to the parameters
     the next forward reads) and the points never interact, so the list returned equals the K separate calls."""
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
-    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, False)
+    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, False).result()
     K = res.shape[0]
     R = ops.rot_from_ypr(res[:, 3:6])
     host = torch.cat([res[:, 0:3], R.reshape(K, 9), res[:, 12:13]], dim=1).cpu()
@@ -270,14 +293,12 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     if strict_reference_asserts:
         assert cfg.num_input > 1
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
-    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, True)      # (B, 14) on the GPU
-    k = torch.argmin(res[:, 12])            # loss_list.argmin() of the last forward
-    win = res[k]
-    R = _rot_matrix(win[3:6])
-    out = torch.cat([win[0:3], R.reshape(-1), win[12:13]]).cpu()     # the one D2H copy of the whole refinement
-    with torch.no_grad():
-        input_trans.copy_(res[:, 6:9].to(input_trans.device))
-        input_rot.copy_(res[:, 9:12].to(input_rot.device))
+    gd = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, True)
+    # loss_list.argmin() of the last forward, R of the winner and the write-back of the leaves: one kernel, then the one D2H copy
+    # of the whole refinement (64 bytes)
+    bt, br, after = _leaf_buffers(input_trans, input_rot, gd.B)
+    out = gd.winner(1, bt, br)[0].cpu()
+    after()
     return [out[0:3].reshape(3, 1).clone(), out[3:12].reshape(3, 3).clone(), out[12].clone()]
 
 
@@ -300,15 +321,13 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
     tr = torch.cat([ops._dev(t).reshape(B, 3) for t in input_trans_list])
     ro = torch.cat([ops._dev(r).reshape(B, 3) for r in input_rot_list])
-    res = _refine(xyz, rgb, [panos[i] for i in range(I) for _ in range(B)], tr, ro, box, cfg, batch_mode).reshape(I, B, -1)
-    k = torch.argmin(res[:, :, 12], dim=1)
-    win = torch.gather(res, 1, k.reshape(-1, 1, 1).expand(-1, 1, res.shape[2]))[:, 0]        # (I, 14)
-    R = ops.rot_from_ypr(win[:, 3:6])                                                        # (I, 3, 3)
-    host = torch.cat([win[:, 0:3], R.reshape(I, 9), win[:, 12:13]], dim=1).cpu()
+    gd = _refine(xyz, rgb, panos, tr, ro, box, cfg, batch_mode)
+    leaf_t, leaf_r = torch.empty(I * B, 3, dtype=torch.float32, device=tr.device), torch.empty(I * B, 3, dtype=torch.float32, device=tr.device)
+    host = gd.winner(I, leaf_t, leaf_r).cpu()                # per image: the smallest last loss (omniloc.py:271), one D2H copy
     with torch.no_grad():
         for i in range(I):
-            input_trans_list[i].copy_(res[i, :, 6:9].to(input_trans_list[i].device))
-            input_rot_list[i].copy_(res[i, :, 9:12].to(input_rot_list[i].device))
+            input_trans_list[i].copy_(leaf_t[i * B:(i + 1) * B].to(input_trans_list[i].device))
+            input_rot_list[i].copy_(leaf_r[i * B:(i + 1) * B].to(input_rot_list[i].device))
     return [[host[i, 0:3].reshape(3, 1).clone(), host[i, 3:12].reshape(3, 3).clone(), host[i, 12].clone()] for i in range(I)]
 
 

@@ -182,6 +182,43 @@ def trim_loss_table(cloud, pano, trans, groups, return_count=False):
     return (table, count) if return_count else table
 
 
+def select_poses(values, n_keep, trans, rot, largest=False, rot_per_trans=0, return_idx=False):
+    """The selections of the initialisation stage (utils.py:500-505 / :583-586) in one launch: values (M,) or (P, M) -> the
+    n_keep best rows (trans[idx // rot_per_trans], rot[idx % rot_per_trans]) — or (trans[idx], rot[idx]) when rot_per_trans is 0
+    — in rank order, as ((P,) n_keep, 3) tensors.  Stable order; NaN ranks last.  With (P, M) values, trans / rot are either shared
+    2-D tables or (P, rows, 3) stacks."""
+    lib = _lib.load()
+    values = _dev(values)
+    single = values.dim() == 1
+    v = values.reshape(1, -1) if single else values.reshape(values.shape[0], -1)
+    P, M = int(v.shape[0]), int(v.shape[1])
+    trans, rot = _dev(trans), _dev(rot)
+    stride = 0
+    if trans.dim() == 3:
+        if rot.dim() != 3 or trans.shape[0] != P or rot.shape[:2] != trans.shape[:2]:
+            raise ValueError("select_poses: per-problem pose tables must be (P, rows, 3) for both trans and rot")
+        stride = int(trans.shape[1])
+    trans, rot = trans.reshape(-1, 3), rot.reshape(-1, 3)
+    rows_t = trans.shape[0] if stride == 0 else stride
+    rows_r = rot.shape[0] if stride == 0 else stride
+    need_t = (M + rot_per_trans - 1) // rot_per_trans if rot_per_trans > 0 else M
+    need_r = rot_per_trans if rot_per_trans > 0 else M
+    if rows_t < need_t or rows_r < need_r:
+        raise ValueError("select_poses: %d values need %d translations and %d rotations" % (M, need_t, need_r))
+    n_keep = int(n_keep)
+    ot = torch.empty(P, n_keep, 3, dtype=F32, device=v.device)
+    orr = torch.empty(P, n_keep, 3, dtype=F32, device=v.device)
+    oi = torch.empty(P, n_keep, dtype=torch.int32, device=v.device) if return_idx else None
+    _lib.check(lib.pcl_select_poses(_ptr(v), P, M, n_keep, 1 if largest else 0, _ptr(trans), _ptr(rot), int(rot_per_trans), stride,
+                                    _ptr(ot), _ptr(orr), _ptr(oi), _stream()), "pcl_select_poses")
+    if single:
+        ot, orr, oi = ot[0], orr[0], (oi[0] if oi is not None else None)
+    return (ot, orr, oi) if return_idx else (ot, orr)
+
+
+SELECT_MAX_KEEP = 1024      # pcl_select_poses: winners per problem (include/piccolo_hip.h)
+
+
 def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
     `cloud` is a packed Cloud.  Candidates are processed `batch` at a time.  Workspace per candidate: the point lists of the
@@ -397,6 +434,35 @@ class GradientDescent:
         assert table.dtype == torch.int64 and table.numel() == self.B and table.is_cuda
         _lib.check(_lib.load().pcl_gd_set_panos(_ptr(self.state), _ptr(table), self.B, _stream()), "pcl_gd_set_panos")
         self._pano_table = table
+
+    def set_pano_groups(self, panos):
+        """Candidates [i * B / I, (i + 1) * B / I) sample panos[i] (I Pano objects of the size / texel format of self.pano, B
+        divisible by I).  Unlike set_panos / set_pano_table nothing is copied to the device: the addresses are kernel arguments."""
+        lib = _lib.load()
+        I = len(panos)
+        if I <= 0 or self.B % I:
+            raise ValueError("set_pano_groups: %d candidates do not split into %d images" % (self.B, I))
+        for p in panos:
+            if (p.H, p.W, p.fmt) != (self.pano.H, self.pano.W, self.pano.fmt):
+                raise ValueError("all panoramas of a launch must share size and texel format")
+        self._panos = list(panos)                      # keep them alive
+        arr = (ctypes.c_uint64 * I)(*[p.data.data_ptr() for p in panos])
+        _lib.check(lib.pcl_gd_set_pano_groups(_ptr(self.state), arr, I, self.B // I, _stream()), "pcl_gd_set_pano_groups")
+
+    def winner(self, nimages=1, leaf_trans=None, leaf_rot=None):
+        """(nimages, 16) GPU tensor, per image of B / nimages candidates the one omniloc_batch returns (omniloc.py:271-277):
+        post-step t (3), R (9), last loss, yaw / pitch / roll.  leaf_trans / leaf_rot: contiguous float32 GPU tensors of B x 3
+        that receive every candidate's leaf parameters (the reference optimises the caller's rows in place)."""
+        lib = _lib.load()
+        if nimages <= 0 or self.B % nimages:
+            raise ValueError("winner: %d candidates do not split into %d images" % (self.B, nimages))
+        out = torch.empty(nimages, 16, dtype=F32, device=self.state.device)
+        for t in (leaf_trans, leaf_rot):
+            if t is not None and not (t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.numel() == 3 * self.B):
+                raise ValueError("winner: leaf buffers must be contiguous float32 GPU tensors of B x 3")
+        _lib.check(lib.pcl_gd_winner(_ptr(self.state), nimages, self.B // nimages, _ptr(out), _ptr(leaf_trans), _ptr(leaf_rot), _stream()),
+                   "pcl_gd_winner")
+        return out
 
     def result(self):
         """(B, 14): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr."""

@@ -186,8 +186,12 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
         table = torch.cat([ops.sampling_loss(cloud, pano, tr[k0:k0 + rows].repeat_interleave(Rn, 0), ro.repeat(min(rows, K - k0), 1),
                                              with_grad=False)[:, 0] for k0 in range(0, K, rows)])
     num_input = min(num_input, K * Rn)
-    # loss_table.argsort()[:num_input] (utils.py:500-501); topk is one selection kernel where argsort of a few thousand
-    # values runs ~100 tiny merge-sort launches (1 ms per image); NaN losses (nothing sampled) rank last in both
+    # loss_table.flatten().argsort()[:num_input] and the `// len(rot)`, `% len(rot)` decode (utils.py:500-505) in ONE launch
+    # (pcl_select_poses: radix select + rank + gather; torch.topk + sort + four index kernels took 110 us per image for 7 KB of
+    # data); NaN losses (nothing sampled) rank last, as in the reference's argsort
+    if num_input <= ops.SELECT_MAX_KEEP:
+        tt, tr = ops.select_poses(table, num_input, trans, rot, largest=False, rot_per_trans=Rn)
+        return _like(tt, trans), _like(tr, rot)
     min_inds = torch.topk(table, num_input, largest=False, sorted=True).indices.to(trans.device)
     return trans[torch.div(min_inds, Rn, rounding_mode="floor")], rot[min_inds % Rn]
 
@@ -197,7 +201,11 @@ def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h,
     block-wise colour-histogram intersection with the query image.  All candidates go through three fused kernels
     (csrc/pcl_hist.hip): batched z-buffer splat, query histograms, per-(candidate, block) LDS histogram + intersection."""
     scores = ops.hist_trim_scores(img, packed_cloud(xyz, rgb), trans, rot, num_split_h, num_split_w)
-    order = torch.topk(scores, min(num_input, scores.numel()), largest=True, sorted=True).indices.to(trans.device)   # best first
+    n = min(num_input, scores.numel())
+    if n <= ops.SELECT_MAX_KEEP:                    # flip(argsort()[-n:]) and the two gathers (utils.py:583-586) in one launch
+        tt, tr = ops.select_poses(scores, n, trans, rot, largest=True)
+        return _like(tt, trans), _like(tr, rot)
+    order = torch.topk(scores, n, largest=True, sorted=True).indices.to(trans.device)   # best first
     return trans[order], rot[order]
 
 

@@ -261,6 +261,100 @@ def test_make_input_composed_matches_the_reference(oracle, parity):
             check_selection(dist.argmin(1), d["hist_hist_intersect"], n_in, np.abs(scores - d["hist_hist_intersect"]) + 1e-6, largest=True)
 
 
+def test_select_poses_is_the_reference_argsort_and_decode():
+    """pcl_select_poses against numpy's stable argsort: utils.py:500-505 (ascending, `// len(rot)`, `% len(rot)`) and
+    utils.py:583-586 (the flipped tail of the ascending argsort), with ties, NaNs (ranked last), -0.0 / +0.0, negative values,
+    n_keep = 1, = M and the 1024 limit, several problems per launch with shared and with per-problem pose tables."""
+    from piccolo_amd import ops
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda")
+
+    def ref_order(v, n, largest):
+        key = np.where(np.isnan(v), np.inf, v).astype(np.float64)
+        if not largest:
+            return np.argsort(key, kind="stable")[:n]
+        key = np.where(np.isnan(v), -np.inf, v).astype(np.float64)
+        return np.argsort(key, kind="stable")[-n:][::-1]
+
+    for K, R, n in ((75, 24, 50), (165, 8, 50), (7, 3, 21), (1, 1, 1), (300, 5, 1024), (2000, 1, 6)):
+        M = K * R
+        v = rng.normal(size=M).astype(np.float32)
+        v[rng.integers(0, M, M // 10)] = np.float32(0.25)              # ties
+        v[rng.integers(0, M, max(1, M // 50))] = np.nan
+        if M > 4:
+            v[1], v[3] = np.float32(-0.0), np.float32(0.0)
+        n = min(n, M)
+        trans, rot = rng.normal(size=(K, 3)).astype(np.float32), rng.normal(size=(R, 3)).astype(np.float32)
+        tt, tr, idx = ops.select_poses(torch.from_numpy(v).to(dev), n, torch.from_numpy(trans).to(dev), torch.from_numpy(rot).to(dev),
+                                       largest=False, rot_per_trans=R, return_idx=True)
+        want = ref_order(v, n, False)
+        assert np.array_equal(idx.cpu().numpy(), want), (K, R, n)
+        assert np.array_equal(tt.cpu().numpy(), trans[want // R]) and np.array_equal(tr.cpu().numpy(), rot[want % R])
+        # the second stage's form: one pose row per value, best first
+        pt, pr = rng.normal(size=(M, 3)).astype(np.float32), rng.normal(size=(M, 3)).astype(np.float32)
+        tt, tr, idx = ops.select_poses(torch.from_numpy(v).to(dev), n, torch.from_numpy(pt).to(dev), torch.from_numpy(pr).to(dev),
+                                       largest=True, return_idx=True)
+        want = ref_order(v, n, True)
+        assert np.array_equal(idx.cpu().numpy(), want), (K, R, n, "largest")
+        assert np.array_equal(tt.cpu().numpy(), pt[want]) and np.array_equal(tr.cpu().numpy(), pr[want])
+    # several problems per launch
+    P, M, n = 5, 1800, 50
+    v = rng.normal(size=(P, M)).astype(np.float32)
+    trans, rot = rng.normal(size=(75, 3)).astype(np.float32), rng.normal(size=(24, 3)).astype(np.float32)
+    tt, tr, idx = ops.select_poses(torch.from_numpy(v).to(dev), n, torch.from_numpy(trans).to(dev), torch.from_numpy(rot).to(dev),
+                                   rot_per_trans=24, return_idx=True)
+    for p in range(P):
+        want = ref_order(v[p], n, False)
+        assert np.array_equal(idx[p].cpu().numpy(), want)
+        assert np.array_equal(tt[p].cpu().numpy(), trans[want // 24]) and np.array_equal(tr[p].cpu().numpy(), rot[want % 24])
+    pt, pr = rng.normal(size=(P, 64, 3)).astype(np.float32), rng.normal(size=(P, 64, 3)).astype(np.float32)
+    sc = rng.uniform(size=(P, 64)).astype(np.float32)
+    tt, tr = ops.select_poses(torch.from_numpy(sc).to(dev), 6, torch.from_numpy(pt).to(dev), torch.from_numpy(pr).to(dev), largest=True)
+    for p in range(P):
+        want = ref_order(sc[p], 6, True)
+        assert np.array_equal(tt[p].cpu().numpy(), pt[p][want]) and np.array_equal(tr[p].cpu().numpy(), pr[p][want])
+    with pytest.raises(Exception):
+        ops.select_poses(torch.zeros(10, device=dev), 11, torch.zeros(10, 3, device=dev), torch.zeros(10, 3, device=dev))
+
+
+def test_gd_winner_is_argmin_of_the_last_losses_with_its_rotation():
+    """pcl_gd_winner (omniloc.py:271-277 on the device) against the host-side form it replaces: torch.argmin over the last
+    losses, rot_from_ypr of the winner, leaf parameters of all candidates — for one image and for 3 images x 4 candidates."""
+    from piccolo_amd import ops, synth
+    n, H, W = 20_000, 64, 128
+    xyz, rgb = synth.box_room(n, 2)
+    dev = torch.device("cuda")
+    X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+    cloud = ops.Cloud(X, C)
+    panos, tr, ro = [], [], []
+    for i in range(3):
+        t_gt, ypr_gt = synth.gt_pose(20 + i)
+        img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
+        panos.append(ops.Pano(img))
+        a, b = synth.start_poses(t_gt, ypr_gt, 4, seed=i)
+        tr.append(a); ro.append(b)
+    box = ops.quantile_box(X, 0.05)
+    for nimg in (1, 3):
+        T_, R_ = torch.from_numpy(np.concatenate(tr[:nimg])).to(dev), torch.from_numpy(np.concatenate(ro[:nimg])).to(dev)
+        gd = ops.GradientDescent(cloud, panos[0], T_, R_, box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
+        gd.set_pano_groups(panos[:nimg])
+        gd.run(7)
+        res = gd.result()
+        # the same chain with the device-table form of the panorama list gives the same bits
+        gd2 = ops.GradientDescent(cloud, panos[0], T_, R_, box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
+        gd2.set_panos([panos[i] for i in range(nimg) for _ in range(4)])
+        gd2.run(7)
+        assert torch.equal(res, gd2.result())
+        lt, lr_ = torch.empty(4 * nimg, 3, device=dev), torch.empty(4 * nimg, 3, device=dev)
+        win = gd.winner(nimg, lt, lr_)
+        assert torch.equal(lt, res[:, 6:9]) and torch.equal(lr_, res[:, 9:12])
+        for i in range(nimg):
+            blk = res[4 * i:4 * i + 4]
+            k = int(torch.argmin(blk[:, 12]))
+            assert torch.equal(win[i, 0:3], blk[k, 0:3]) and torch.equal(win[i, 13:16], blk[k, 3:6]) and win[i, 12] == blk[k, 12]
+            assert torch.equal(win[i, 3:12], ops.rot_from_ypr(blk[k:k + 1, 3:6])[0].reshape(-1))
+
+
 def _run_bench(cmd, env_extra, timeout=900):
     import json as js
     import os
