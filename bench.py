@@ -469,28 +469,86 @@ def pipeline_block(sc, n_images=3, num_input=32, num_intermediate=64):
         lr, num_iter, patience, factor, out_of_room_quantile = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE
     Cfg.num_input = num_input
 
-    rows = []
+    rows, totals = [], []
+    imgs = []
     for j in range(n_images + 1):
         e = sc.image(2_000_000 + j, keep_img=True)
-        img = e["img"]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tr, ro = utils.make_input(img, sc.X, sc.C, num_input, STANFORD_INIT, "loss_histogram", num_intermediate)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        res = po.omniloc_batch(img, sc.X, sc.C, tr, ro, Cfg(), {})
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        te, re = synth.pose_errors(res[0].numpy(), res[1].numpy(), e["gt"][0], synth.rot_from_ypr_np(e["gt"][1]))
-        if j > 0:
-            rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, te, re))
+        imgs.append((e["img"], e["gt"]))
         del e["img"]
+    for stage_sync in (True, False):
+        for j, (img, gt) in enumerate(imgs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr, ro = utils.make_input(img, sc.X, sc.C, num_input, STANFORD_INIT, "loss_histogram", num_intermediate)
+            if stage_sync:
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = po.omniloc_batch(img, sc.X, sc.C, tr, ro, Cfg(), {})
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if j == 0:
+                continue                                     # untimed: first image of the pass
+            if stage_sync:
+                te, re = synth.pose_errors(res[0].numpy(), res[1].numpy(), gt[0], synth.rot_from_ypr_np(gt[1]))
+                rows.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, te, re))
+            else:
+                totals.append((t2 - t0) * 1e3)
     rows = np.array(rows)
     return {"what": "per query image (%d points, %dx%d): make_input (75 x 24 = 1800-pose grid -> %d -> %d) + omniloc_batch (%d candidates x "
                     "100 iterations), medians over %d images" % (sc.N, sc.W, sc.H, num_intermediate, num_input, num_input, n_images),
+            "total_ms": float(np.median(totals)),
+            "total_is": "one clock around make_input + omniloc_batch, as the reference's `time (s)` column is taken (localize.py:208,222-223): "
+                        "no device synchronisation between the two calls; the stage times below come from a second pass with one",
             "make_input_ms": float(np.median(rows[:, 0])), "refine_ms": float(np.median(rows[:, 1])),
-            "total_ms": float(np.median(rows[:, 0] + rows[:, 1])),
+            "total_with_stage_sync_ms": float(np.median(rows[:, 0] + rows[:, 1])),
             "median_t_err_m": float(np.median(rows[:, 2])), "median_r_err_deg": float(np.median(rows[:, 3]))}
+
+
+def pipeline_images_block(sc, ipl=8, n_groups=3, num_input=6, num_intermediate=50):
+    """The same pipeline for `ipl` query images of the room at a time, through the product's multi-image surface (what the dataset
+    loops run with cfg images_per_launch): make_input_images (one trim launch over image x translation x rotation, one selection
+    launch) + omniloc_batch_images (all ipl x num_input candidates in one launch chain).  ms per image, median over `n_groups`
+    groups after one untimed group."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import utils
+
+    class Cfg:
+        lr, num_iter, patience, factor, out_of_room_quantile = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE
+    Cfg.num_input = num_input
+
+    groups = []
+    for g in range(n_groups + 1):
+        imgs, gts = [], []
+        for j in range(ipl):
+            e = sc.image(3_000_000 + g * ipl + j, keep_img=True)
+            imgs.append(e.pop("img"))
+            gts.append(e["gt"])
+        groups.append((imgs, gts))
+    rows, errs = [], []
+    for stage_sync in (True, False):
+        for g, (imgs, gts) in enumerate(groups):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            starts = utils.make_input_images(imgs, sc.X, sc.C, num_input, STANFORD_INIT, "loss_histogram", num_intermediate)
+            if stage_sync:
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = po.omniloc_batch_images(imgs, sc.X, sc.C, [s[0] for s in starts], [s[1] for s in starts], Cfg())
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if g == 0:
+                continue
+            rows.append((stage_sync, (t1 - t0) * 1e3 / ipl, (t2 - t1) * 1e3 / ipl, (t2 - t0) * 1e3 / ipl))
+            if stage_sync:
+                errs += [synth.pose_errors(r[0].numpy(), r[1].numpy(), gt[0], synth.rot_from_ypr_np(gt[1])) for r, gt in zip(res, gts)]
+    rows, errs = np.array(rows), np.array(errs)
+    staged, free = rows[rows[:, 0] == 1], rows[rows[:, 0] == 0]
+    return {"what": "per query image, %d images of the room at a time (%d points, %dx%d): make_input_images (1800-pose grid -> %d -> %d per image) "
+                    "+ omniloc_batch_images (%d x %d candidates x 100 iterations in one launch chain), medians over %d groups"
+                    % (ipl, sc.N, sc.W, sc.H, num_intermediate, num_input, ipl, num_input, n_groups),
+            "images_per_launch": ipl, "total_ms_per_image": float(np.median(free[:, 3])),
+            "make_input_ms_per_image": float(np.median(staged[:, 1])), "refine_ms_per_image": float(np.median(staged[:, 2])),
+            "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1]))}
 
 
 def main():
@@ -702,6 +760,7 @@ def main():
                 also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
             if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
                 also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
+                also["pipeline_shipped_8_images"] = pipeline_images_block(scenes[(166_667, 1024, 2048)], ipl=8)
             if args.workload != "cfg5" and world == 1:
                 also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
         except Exception as exc:                        # the headline must survive a failing side measurement

@@ -263,6 +263,14 @@ size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups);
 int pcl_trim_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans, int K,
                   const float *rot, int R, const void *groups, int ngroups, float *loss_table, float *count_table,
                   void *workspace, size_t workspace_bytes, void *stream);
+/* The same for `nimages` query images of ONE room in one launch (the image loop of localize.py:143-223: the candidate grid
+ * depends on the cloud only, utils.py:613-616): panos_host = HOST array of nimages device addresses of packed panoramas (one
+ * size and texel format; nimages <= 32), loss_tables / count_tables [nimages][K][R].  The cloud is cut into the chunks of the
+ * single-image launch, so every image's table has the bits pcl_trim_loss gives it. */
+size_t pcl_trim_loss_images_workspace_bytes(int64_t n, int K, int ngroups, int nimages);
+int pcl_trim_loss_images(const float *cloud, int64_t n, const void *const *panos_host, int nimages, int pano_format, int H, int W,
+                         const float *trans, int K, const float *rot, int R, const void *groups, int ngroups, float *loss_tables,
+                         float *count_tables, void *workspace, size_t workspace_bytes, void *stream);
 /* Scatter-min depth mask on the PACKED cloud for B poses (build-defined, off by default in the loss):
  * visible[b][i] = 1 iff point i (packed order) is within (1 + tau) of the nearest point that falls into the same
  * make_pano pixel (utils.py:158-165) of an H x W panorama seen from pose b.  Feeds the `visible` argument of

@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(PCL_SEL_THREADS) pcl_select_kernel(const float
 {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long prefix_sh;
-    __shared__ unsigned need_sh, nwin_sh;
+    __shared__ unsigned need_sh, nwin_sh, wave_tot[4];
     __shared__ unsigned long long win[PCL_SEL_MAX_KEEP];
     const int p = blockIdx.x, tid = threadIdx.x;
     const float* v = values + (long long)p * M;
@@ -52,15 +52,30 @@ __global__ void __launch_bounds__(PCL_SEL_THREADS) pcl_select_kernel(const float
             if ((c & high_mask) == prefix) atomicAdd(&hist[(unsigned)(c >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = need_sh, acc = 0u;
-            int b = 0;
-            for (; b < 256; b++) {
-                if (acc + hist[b] >= need) break;
-                acc += hist[b];
+        // the bucket that holds the wanted rank: inclusive scan of the 256 counts (wave scans + the four wave totals), then the
+        // one thread whose bucket spans the rank publishes it (a serial walk by one thread cost 5 - 9 us per pass)
+        const unsigned need = need_sh;
+        unsigned h = 0u, incl = 0u;
+        if (tid < 256) {
+            h = hist[tid];
+            incl = h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned up = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d) incl += up;
             }
-            prefix_sh = prefix | ((unsigned long long)b << shift);
-            need_sh = need - acc;                                     // rank of the wanted composite inside bucket b
+            if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned before = 0u;
+            for (int w = 0; w < (tid >> 6); w++) before += wave_tot[w];
+            incl += before;
+            const unsigned excl = incl - h;
+            if (excl < need && need <= incl) {                        // exactly one bucket
+                prefix_sh = prefix | ((unsigned long long)tid << shift);
+                need_sh = need - excl;                                // rank of the wanted composite inside this bucket
+            }
         }
         __syncthreads();
     }

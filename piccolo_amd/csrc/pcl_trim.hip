@@ -185,16 +185,19 @@ __global__ void pcl_trim_pose_setup_kernel(const float* __restrict__ trans, cons
 }
 
 // ---------------------------------------------------------------- the forward pass
+#define PCL_TRIM_MAX_IMAGES 32      // query images per launch (their packed panoramas' addresses travel as kernel arguments)
+
 struct PclTrimArgs {
     const float* cloud;
     int64_t n, stride;
-    const void* pano;
+    const void* pano[PCL_TRIM_MAX_IMAGES];   // image i is evaluated by the blocks whose slot index falls into [i * nslots, (i + 1) * nslots)
+    int nimages;
     PclDims dims;
     const PclPoseRec* poses;         // [ngroups * K]
     const PclTrimHeader* hdr;
     const PclTrimGroup* groups;
-    int K, nslots;                   // nslots = ngroups (host's count) * K
-    float* partials;                 // [nchunks][nslots][PCL_TRIM_Y][2]
+    int K, nslots;                   // nslots = ngroups (host's count) * K, per image
+    float* partials;                 // [nchunks][nimages * nslots][PCL_TRIM_Y][2]
     int nchunks, seg_len, steps_base, steps_rem;
 };
 
@@ -229,12 +232,16 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
 {
     // same XCD-aware mapping as pcl_loss_kernel: blocks b and b + 8 share an XCD; within an XCD the slot varies fastest, so the
     // blocks resident together read the same cloud chunk; consecutive slots are neighbouring translations of one class
-    const int lq = (int)(blockIdx.x >> 3) / a.nslots, slot = (int)(blockIdx.x >> 3) - lq * a.nslots;
+    // (several query images in one launch: the slot index runs over image x (group, translation); the chunks are those of the
+    //  single-image launch, so every (image, slot, chunk) partial sum — and with it the table — has the single-image launch's bits)
+    const int nslots_all = a.nimages * a.nslots;
+    const int lq = (int)(blockIdx.x >> 3) / nslots_all, slot_all = (int)(blockIdx.x >> 3) - lq * nslots_all;
+    const int image = slot_all / a.nslots, slot = slot_all - image * a.nslots;
     const int run = lq / a.seg_len;
     const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lq - run * a.seg_len);
     const int g = slot / a.K;
     const PclTrimGroup* __restrict__ gr = a.groups + g;
-    float* out = a.partials + ((int64_t)chunk * a.nslots + slot) * PCL_NACC;
+    float* out = a.partials + ((int64_t)chunk * nslots_all + slot_all) * PCL_NACC;
     if (g >= a.hdr->ngroups) {                                   // (the host's group count is an upper bound)
         if (threadIdx.x < PCL_NACC) out[threadIdx.x] = 0.f;
         return;
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
     const int ny = gr->ny;
     const PclPoseRec* __restrict__ pose = a.poses + slot;
 
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
+    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano[image], a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
     const int plane = (int)a.stride * 4;
 
@@ -361,13 +368,14 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
 }
 
 // loss_table[k][rot] = sum ||d|| / count over the chunks (fixed order, double): one thread per (slot, yaw)
-__global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __restrict__ partials, int nchunks, int nslots, int K, int R,
+__global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __restrict__ partials, int nchunks, int nslots, int nimages, int K, int R,
                                                               const PclTrimHeader* __restrict__ hdr, const PclTrimGroup* __restrict__ groups,
                                                               float* __restrict__ loss_table, float* __restrict__ count_table)
 {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nslots * PCL_TRIM_Y) return;
-    const int slot = id / PCL_TRIM_Y, y = id - slot * PCL_TRIM_Y;
+    if (id >= nimages * nslots * PCL_TRIM_Y) return;
+    const int slot_all = id / PCL_TRIM_Y, y = id - slot_all * PCL_TRIM_Y;
+    const int image = slot_all / nslots, slot = slot_all - image * nslots;
     const int g = slot / K, k = slot - g * K;
     // a `groups` blob of another rotation table, or more groups than the caller launched: nothing is written and the table
     // keeps the NaNs pcl_trim_loss filled it with (a stale or partly filled table must not rank)
@@ -375,34 +383,44 @@ __global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __res
     if (g >= hdr->ngroups || y >= groups[g].ny) return;
     double s0 = 0.0, s1 = 0.0;
     for (int c = 0; c < nchunks; c++) {
-        const float* p = partials + ((int64_t)c * nslots + slot) * PCL_NACC + 2 * y;
+        const float* p = partials + ((int64_t)c * nimages * nslots + slot_all) * PCL_NACC + 2 * y;
         s0 += (double)p[0]; s1 += (double)p[1];
     }
     const int j = groups[g].rot_idx[y];
-    loss_table[(int64_t)k * R + j] = (float)s0 / (float)s1;           // 0 / 0 = NaN like the reference's mean of nothing
-    if (count_table) count_table[(int64_t)k * R + j] = (float)s1;
+    const int64_t o = ((int64_t)image * K + k) * R + j;
+    loss_table[o] = (float)s0 / (float)s1;                            // 0 / 0 = NaN like the reference's mean of nothing
+    if (count_table) count_table[o] = (float)s1;
 }
 
 static size_t trim_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups)
+static size_t trim_workspace_bytes(int64_t n, int K, int ngroups, int nimages)
 {
-    if (n <= 0 || K <= 0 || ngroups <= 0) return 0;
+    if (n <= 0 || K <= 0 || ngroups <= 0 || nimages <= 0) return 0;
     int nchunks, seg_len, sb, sr;
     pcl_plan_for_groups(n, ngroups * K, &nchunks, &seg_len, &sb, &sr);
-    return trim_align((size_t)ngroups * K * sizeof(PclPoseRec)) + trim_align((size_t)nchunks * ngroups * K * PCL_NACC * sizeof(float));
+    return trim_align((size_t)ngroups * K * sizeof(PclPoseRec)) + trim_align((size_t)nchunks * nimages * ngroups * K * PCL_NACC * sizeof(float));
 }
 
-extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans, int K,
-                             const float* rot, int R, const void* groups, int ngroups, float* loss_table, float* count_table,
-                             void* workspace, size_t workspace_bytes, void* stream)
+extern "C" size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups) { return trim_workspace_bytes(n, K, ngroups, 1); }
+extern "C" size_t pcl_trim_loss_images_workspace_bytes(int64_t n, int K, int ngroups, int nimages)
 {
-    if (!cloud || !pano || !trans || !rot || !groups || !loss_table || !workspace) return PCL_EINVAL;
+    return nimages <= PCL_TRIM_MAX_IMAGES ? trim_workspace_bytes(n, K, ngroups, nimages) : 0;
+}
+
+extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* const* panos_host, int nimages, int pano_format, int H, int W,
+                                    const float* trans, int K, const float* rot, int R, const void* groups, int ngroups, float* loss_tables,
+                                    float* count_tables, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !panos_host || !trans || !rot || !groups || !loss_tables || !workspace) return PCL_EINVAL;
+    if (nimages <= 0 || nimages > PCL_TRIM_MAX_IMAGES) return PCL_EINVAL;
+    for (int i = 0; i < nimages; i++)
+        if (!panos_host[i]) return PCL_EINVAL;
     if (n <= 0 || n > PCL_MAX_POINTS || K <= 0 || R <= 0 || ngroups <= 0 || ngroups > R || H <= 0 || W <= 0) return PCL_EINVAL;
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     if ((int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
-    if ((int64_t)ngroups * K > (1 << 24)) return PCL_EINVAL;
-    if (workspace_bytes < pcl_trim_loss_workspace_bytes(n, K, ngroups)) return PCL_EWORKSPACE;
+    if ((int64_t)ngroups * K * nimages > (1 << 24)) return PCL_EINVAL;
+    if (workspace_bytes < trim_workspace_bytes(n, K, ngroups, nimages)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const PclTrimHeader* hdr = (const PclTrimHeader*)groups;
     const PclTrimGroup* grs = (const PclTrimGroup*)(hdr + 1);
@@ -411,22 +429,33 @@ extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, in
     float* partials = (float*)((char*)workspace + trim_align((size_t)nslots * sizeof(PclPoseRec)));
     // every entry starts as NaN (0xFFFFFFFF): what the finish kernel does not write — `ngroups` below the table's group count,
     // a blob built from another table — ranks last in the caller's selection instead of as whatever the buffer held
-    hipError_t me = hipMemsetAsync(loss_table, 0xFF, (size_t)K * R * sizeof(float), s);
-    if (me == hipSuccess && count_table) me = hipMemsetAsync(count_table, 0, (size_t)K * R * sizeof(float), s);
+    hipError_t me = hipMemsetAsync(loss_tables, 0xFF, (size_t)nimages * K * R * sizeof(float), s);
+    if (me == hipSuccess && count_tables) me = hipMemsetAsync(count_tables, 0, (size_t)nimages * K * R * sizeof(float), s);
     if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(pcl_trim_pose_setup_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, trans, rot, K, hdr, grs, ngroups, recs);
     PclTrimArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
-    a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
+    for (int i = 0; i < PCL_TRIM_MAX_IMAGES; i++) a.pano[i] = i < nimages ? panos_host[i] : nullptr;
+    a.nimages = nimages;
+    a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = recs; a.hdr = hdr; a.groups = grs; a.K = K; a.nslots = nslots; a.partials = partials;
+    // the chunks of the SINGLE-image launch, whatever the number of images: per-image tables keep that launch's bits
     pcl_plan_for_groups(n, nslots, &a.nchunks, &a.seg_len, &a.steps_base, &a.steps_rem);
-    const int64_t nblk = (int64_t)a.nchunks * nslots;
+    const int64_t nblk = (int64_t)a.nchunks * nslots * nimages;
     if (nblk > 0x7fffffffll) return PCL_EINVAL;
     if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_F16) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F16>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F32>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(pcl_trim_finish_kernel, dim3((nslots * PCL_TRIM_Y + 255) / 256), dim3(256), 0, s, partials, a.nchunks, nslots, K, R,
-                       hdr, grs, loss_table, count_table);
+    hipLaunchKernelGGL(pcl_trim_finish_kernel, dim3((nimages * nslots * PCL_TRIM_Y + 255) / 256), dim3(256), 0, s, partials, a.nchunks, nslots,
+                       nimages, K, R, hdr, grs, loss_tables, count_tables);
     PCL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans, int K,
+                             const float* rot, int R, const void* groups, int ngroups, float* loss_table, float* count_table,
+                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    return pcl_trim_loss_images(cloud, n, &pano, 1, pano_format, H, W, trans, K, rot, R, groups, ngroups, loss_table, count_table, workspace,
+                                workspace_bytes, stream);
 }

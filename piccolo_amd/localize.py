@@ -19,7 +19,7 @@ from . import dist as pdist
 from . import ops, synth
 from .color_utils import color_match, color_mod
 from .omniloc import omniloc_all, omniloc_batch, omniloc_batch_images
-from .utils import make_input, make_pano, out_of_room, resize_image, write_summaries
+from .utils import make_input, make_input_images, make_pano, out_of_room, resize_image, write_summaries
 
 
 def preprocess_colors(img, rgb, cfg):
@@ -269,7 +269,11 @@ def _nan_row():
 
 def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summaries, batcher=None, finish=None, on_start=None):
     """localize.py:199-247: make_input on the initialisation image, refinement on the main image, errors.  With a
-    `batcher` the refinement is deferred: images of one cloud are refined together, `finish(t, R, row)` is called then."""
+    `batcher` BOTH stages are deferred: images of one cloud are initialised together (make_input_images) and refined together
+    (omniloc_batch_images); `finish(t, R, row)` is called then."""
+    if batcher is not None:
+        batcher.submit(dict(img_init=img_init, img=img_main, xyz=xyz, rgb=rgb, gt=(gt_trans, gt_rot), finish=finish, on_start=on_start))
+        return None
     init_dict = get_init_dict(cfg)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -277,11 +281,6 @@ def _refine_and_score(img_init, img_main, xyz, rgb, cfg, gt_trans, gt_rot, summa
                                         getattr(cfg, "criterion", "histogram"), getattr(cfg, "num_intermediate", 20))
     if on_start is not None:
         on_start(input_trans, input_rot)
-    if batcher is not None:
-        torch.cuda.synchronize()
-        batcher.submit(dict(img=img_main, xyz=xyz, rgb=rgb, trans=input_trans, rot=input_rot, gt=(gt_trans, gt_rot),
-                            init_seconds=time.time() - t0, finish=finish))
-        return None
     t, R, loss = refine_image(img_main, xyz, rgb, input_trans, input_rot, cfg, summaries)
     dt = time.time() - t0
     return (t, R) + (_result_row(t, R, loss, gt_trans, gt_rot, dt),)
@@ -303,7 +302,7 @@ class _Batcher:
 
     def submit(self, job):
         if self.jobs and not (job["xyz"] is self.jobs[0]["xyz"] and job["rgb"] is self.jobs[0]["rgb"] and
-                              job["img"].shape == self.jobs[0]["img"].shape and job["trans"].shape == self.jobs[0]["trans"].shape):
+                              job["img"].shape == self.jobs[0]["img"].shape and job["img_init"].shape == self.jobs[0]["img_init"].shape):
             self.flush()
         self.jobs.append(job)
         if len(self.jobs) >= self.size:
@@ -313,17 +312,24 @@ class _Batcher:
         jobs, self.jobs = self.jobs, []
         if not jobs:
             return
+        cfg = self.cfg
         torch.cuda.synchronize()
         t0 = time.time()
+        starts = make_input_images([j["img_init"] for j in jobs], jobs[0]["xyz"], jobs[0]["rgb"], getattr(cfg, "num_input", 6), get_init_dict(cfg),
+                                   getattr(cfg, "criterion", "histogram"), getattr(cfg, "num_intermediate", 20))
+        for j, (tr, ro) in zip(jobs, starts):
+            j["trans"], j["rot"] = tr, ro
+            if j["on_start"] is not None:
+                j["on_start"](tr, ro)
         if len(jobs) == 1:
             j = jobs[0]
-            results = [refine_image(j["img"], j["xyz"], j["rgb"], j["trans"], j["rot"], self.cfg)]
+            results = [refine_image(j["img"], j["xyz"], j["rgb"], j["trans"], j["rot"], cfg)]
         else:
             results = omniloc_batch_images([j["img"] for j in jobs], jobs[0]["xyz"], jobs[0]["rgb"], [j["trans"] for j in jobs],
-                                           [j["rot"] for j in jobs], self.cfg, batch_mode=bool(getattr(self.cfg, "parallel", False)))
-        share = (time.time() - t0) / len(jobs)
+                                           [j["rot"] for j in jobs], cfg, batch_mode=bool(getattr(cfg, "parallel", False)))
+        share = (time.time() - t0) / len(jobs)               # the group's wall time, shared equally (localize.py:208,222-223 per image)
         for j, (t, R, loss) in zip(jobs, results):
-            j["finish"](t, R, _result_row(t, R, loss, j["gt"][0], j["gt"][1], j["init_seconds"] + share))
+            j["finish"](t, R, _result_row(t, R, loss, j["gt"][0], j["gt"][1], share))
 
 
 def localize_stanford(cfg, writer=None, log_dir="./log", root="./data/stanford"):

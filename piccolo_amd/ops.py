@@ -182,6 +182,31 @@ def trim_loss_table(cloud, pano, trans, groups, return_count=False):
     return (table, count) if return_count else table
 
 
+TRIM_MAX_IMAGES = 32       # pcl_trim_loss_images: query images per launch
+
+
+def trim_loss_tables(cloud, panos, trans, groups, return_count=False):
+    """trim_loss_table for several query images of one room in ONE launch: (I, K, R) float GPU tensor; image i's table has the
+    bits of trim_loss_table(cloud, panos[i], ...) (same chunks of the cloud).  panos: list of Pano of one size / texel format."""
+    lib = _lib.load()
+    trans = _dev(trans).reshape(-1, 3)
+    K, I = int(trans.shape[0]), len(panos)
+    p0 = panos[0]
+    if any((p.H, p.W, p.fmt) != (p0.H, p0.W, p0.fmt) for p in panos):
+        raise ValueError("all panoramas of a launch must share size and texel format")
+    table = torch.empty(I, K, groups.R, dtype=F32, device=trans.device)
+    count = torch.empty(I, K, groups.R, dtype=F32, device=trans.device) if return_count else None
+    for i0 in range(0, I, TRIM_MAX_IMAGES):
+        part = panos[i0:i0 + TRIM_MAX_IMAGES]
+        nws = lib.pcl_trim_loss_images_workspace_bytes(cloud.n, K, groups.ngroups, len(part))
+        ws = _bytes(nws)
+        arr = (ctypes.c_void_p * len(part))(*[p.data.data_ptr() for p in part])
+        _lib.check(lib.pcl_trim_loss_images(_ptr(cloud.data), cloud.n, arr, len(part), p0.fmt, p0.H, p0.W, _ptr(trans), K, _ptr(groups.rot),
+                                            groups.R, _ptr(groups.data), groups.ngroups, _ptr(table[i0:]), _ptr(count[i0:]) if return_count else None,
+                                            _ptr(ws), nws, _stream()), "pcl_trim_loss_images")
+    return (table, count) if return_count else table
+
+
 def select_poses(values, n_keep, trans, rot, largest=False, rot_per_trans=0, return_idx=False):
     """The selections of the initialisation stage (utils.py:500-505 / :583-586) in one launch: values (M,) or (P, M) -> the
     n_keep best rows (trans[idx // rot_per_trans], rot[idx % rot_per_trans]) — or (trans[idx], rot[idx]) when rot_per_trans is 0

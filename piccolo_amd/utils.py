@@ -20,7 +20,7 @@ from . import ops
 from .omniloc import packed_cloud, packed_pano
 
 __all__ = ["cloud2idx", "sample_from_img", "warp_from_img", "reshape_img_tensor", "make_pano", "quantile", "out_of_room", "rot_from_ypr", "trim_input_loss",
-           "trim_input_hist_secondary", "make_input", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
+           "trim_input_hist_secondary", "make_input", "make_input_images", "generate_rot_points", "generate_trans_points", "adaptive_trans_num",
            "compute_sampling_grid", "create_coordinate", "write_summaries", "debug_visualize", "resize_image", "get_bound", "defaultdict", "torch", "np"]
 
 
@@ -321,6 +321,41 @@ def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", 
         raise UnboundLocalError("make_input: only criterion='loss_histogram' is implemented (as in the reference)")
     t1, r1 = trim_input_loss(img, xyz, rgb, trans, rot, num_intermediate)
     return trim_input_hist_secondary(img, xyz, rgb, t1, r1, num_input, init_dict["num_split_h"], init_dict["num_split_w"])
+
+
+def make_input_images(imgs, xyz, rgb, num_input, init_dict=None, criterion="histogram", num_intermediate=None):
+    """make_input for SEVERAL query images of one room (throughput extension; the reference's image loop, localize.py:143-223,
+    calls make_input once per image although the candidate grid depends on the cloud only, utils.py:613-616): ONE trim launch
+    over image x translation x rotation, one selection launch for all images, the second stage per image, one final selection.
+    Returns [(input_trans, input_rot)] per image — the tensors make_input returns for that image, bit for bit (the trim launch
+    cuts the cloud into the single-image launch's chunks; tests/test_hip_harness.py)."""
+    from .omniloc import _cached
+    if init_dict["sample_rate_for_init"] is not None:
+        raise NotImplementedError("sample_rate_for_init: broken in the reference too (utils.py:618-620)")
+    if criterion != "loss_histogram":
+        raise UnboundLocalError("make_input: only criterion='loss_histogram' is implemented (as in the reference)")
+    I = len(imgs)
+    dev = imgs[0].device
+    key = repr(sorted((k, str(v)) for k, v in init_dict.items())) + str(dev)
+    rot = _ROT_GRIDS.get(key)
+    if rot is None:
+        rot = _ROT_GRIDS[key] = generate_rot_points(init_dict, device=dev)
+    trans = _cached("grid", (xyz,), lambda: generate_trans_points(xyz, init_dict, device=dev), sub=key)
+    K, Rn = len(trans), len(rot)
+    n_mid = min(num_intermediate, K * Rn)
+    if I == 1 or Rn > ops.TRIM_MAX_ROT or n_mid > ops.SELECT_MAX_KEEP:
+        return [make_input(im, xyz, rgb, num_input, init_dict, criterion, num_intermediate) for im in imgs]
+    cloud = packed_cloud(xyz, rgb)
+    panos = [packed_pano(im, many_poses=True) for im in imgs]
+    if len({p.fmt for p in panos}) > 1:                       # a launch needs one texel format: float4 holds any image
+        panos = [ops.Pano(im, fmt="f32") for im in imgs]
+    groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot))
+    tables = ops.trim_loss_tables(cloud, panos, trans, groups).reshape(I, K * Rn)
+    t1, r1 = ops.select_poses(tables, n_mid, trans, rot, largest=False, rot_per_trans=Rn)               # (I, n_mid, 3)
+    scores = torch.stack([ops.hist_trim_scores(imgs[i], cloud, t1[i], r1[i], init_dict["num_split_h"], init_dict["num_split_w"])
+                          for i in range(I)])
+    ft, fr = ops.select_poses(scores, min(num_input, n_mid), t1, r1, largest=True)                      # (I, num_input, 3)
+    return [(ft[i], fr[i]) for i in range(I)]
 
 
 def debug_visualize(tgt_tensor):

@@ -355,6 +355,43 @@ def test_gd_winner_is_argmin_of_the_last_losses_with_its_rotation():
             assert torch.equal(win[i, 3:12], ops.rot_from_ypr(blk[k:k + 1, 3:6])[0].reshape(-1))
 
 
+def test_make_input_images_equals_per_image_make_input():
+    """make_input_images (one trim launch over image x translation x rotation, one selection launch for all images) returns, for
+    every image, the very tensors make_input returns for it: the multi-image launch cuts the cloud into the single-image launch's
+    chunks, so the loss tables agree bit for bit (also checked directly), and the selections are deterministic."""
+    from piccolo_amd import ops, synth, utils
+    from piccolo_amd.omniloc import packed_cloud, packed_pano
+    n, H, W, I = 40_000, 128, 256, 5
+    xyz, rgb = synth.box_room(n, 4)
+    dev = torch.device("cuda")
+    X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+    imgs = []
+    for i in range(I):
+        t_gt, ypr_gt = synth.gt_pose(40 + i)
+        imgs.append(synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W))))
+    for init in (STANFORD, OMNI):
+        d = dict(init)
+        if d.get("z_prior") is not None:
+            d["z_prior"] = 0.0
+        single = [utils.make_input(im, X, C, 6, d, "loss_histogram", 50) for im in imgs]
+        multi = utils.make_input_images(imgs, X, C, 6, d, "loss_histogram", 50)
+        assert len(multi) == I
+        for (a, b), (c, e) in zip(single, multi):
+            assert torch.equal(a, c) and torch.equal(b, e)
+        rot = utils.generate_rot_points(d, device=dev)
+        trans = utils.generate_trans_points(X, d, device=dev)
+        groups = ops.TrimGroups(rot)
+        cloud = packed_cloud(X, C)
+        panos = [packed_pano(im, many_poses=True) for im in imgs]
+        tabs, cnts = ops.trim_loss_tables(cloud, panos, trans, groups, return_count=True)
+        for i in range(I):
+            t1, c1 = ops.trim_loss_table(cloud, panos[i], trans, groups, return_count=True)
+            assert torch.equal(tabs[i], t1) and torch.equal(cnts[i], c1), i
+    # the dataset loops' batcher goes through it: 3 images per launch
+    with pytest.raises(ValueError):
+        ops.trim_loss_tables(cloud, [panos[0], ops.Pano(imgs[1], fmt="f32")], trans, groups)
+
+
 def _run_bench(cmd, env_extra, timeout=900):
     import json as js
     import os
