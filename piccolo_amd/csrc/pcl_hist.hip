@@ -165,7 +165,30 @@ __device__ __forceinline__ void pcl_bin_tiles(int row, int col, int H, int W, in
 // per block they were most of the kernel (114 / 189 us per 16 candidates at 1M points; a wave-aggregated LDS add instead of
 // one atomic per lane did not help: 130 / 213 us).
 #define PCL_BIN_PTS 2048
-template <bool SCATTER>
+// Pre-dedup (round 4).  Two points of one candidate with the SAME centre pixel splat the same nine cells with the same pass
+// priorities, so the farther one loses every one of them: it can be dropped before it is ever listed.  Morton order puts the
+// points of a pixel next to each other — a far wall seen from the other end of the room has 16 points per pixel, its tile
+// 68 000 list entries (30x the mean: the resolve kernel's tail).  Consecutive lanes hold consecutive Morton points, so a lane
+// compares its (pixel, depth) with the lanes up to PCL_BIN_NEIGH places to either side of it in its row of 16 (DPP row shifts: no
+// LDS, no barrier) and drops out when one of them has the same pixel and a strictly smaller depth.  (Equal depths: both stay.)
+// Count and scatter pass take the same decisions, and the surviving keys are untouched: every cell's winner, hence every score,
+// is bit-identical to the undeduplicated lists (tests: against the z-buffer splat path, which never dedups).  A first version
+// resolved the block's pixels in a 96 x 96 LDS window (exact within the block): resolve 613 -> 454 us per 64 candidates at 1M
+// points, but 138 / 128 us MORE in the count / scatter kernels (window fill, two barriers, 40 KB of LDS) — a net loss.
+// PCL_BIN_DEDUP=0 turns it off (A/B).
+#define PCL_BIN_NEIGH 4
+template <int SH>
+__device__ __forceinline__ bool pcl_bin_dominated_by(uint32_t pix, uint32_t dep)
+{
+    // row_shr:SH = 0x110 + SH (lane i reads lane i - SH of its row), row_shl:SH = 0x100 + SH; lanes without a source keep `old`
+    const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)pix, 0x110 + SH, 0xf, 0xf, false);
+    const uint32_t da = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x110 + SH, 0xf, 0xf, false);
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)pix, 0x100 + SH, 0xf, 0xf, false);
+    const uint32_t db = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x100 + SH, 0xf, 0xf, false);
+    return (int)((pa == pix) & (da < dep)) | (int)((pb == pix) & (db < dep));
+}
+
+template <bool SCATTER, bool DEDUP>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
 {
     constexpr int PER = PCL_BIN_PTS / PCL_BLOCK;
@@ -176,20 +199,37 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cnt[t] = 0;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
-    int tiles[PER][4];
     uint32_t pix[PER], dep[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int64_t i = first + (int64_t)k * PCL_BLOCK;
-#pragma unroll
-        for (int j = 0; j < 4; j++) tiles[k][j] = -1;
+        pix[k] = 0xffffffffu;                          // (row 65535 does not exist: H < 65536)
+        dep[k] = 0u;
         if (i < a.n) {
             int row, col;
             float d;
             pcl_bin_project(a, a.poses + cand, i, row, col, d);
-            pcl_bin_tiles(row, col, a.H, a.W, a.ntx, a.ty_lo, a.ty_hi, tiles[k]);
             pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
             dep[k] = __float_as_uint(d);
+        }
+    }
+    if (DEDUP) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            // (`|`, not `||`: every lane takes part in every DPP read — a short-circuit would switch source lanes off)
+            int dom = (int)pcl_bin_dominated_by<1>(pix[k], dep[k]) | (int)pcl_bin_dominated_by<2>(pix[k], dep[k]);
+            if (PCL_BIN_NEIGH >= 3) dom |= (int)pcl_bin_dominated_by<3>(pix[k], dep[k]);
+            if (PCL_BIN_NEIGH >= 4) dom |= (int)pcl_bin_dominated_by<4>(pix[k], dep[k]);
+            if (dom) pix[k] = 0xffffffffu;             // a nearer point owns this pixel (the compares above all saw the originals:
+        }                                              // k is a different point set per trip)
+    }
+    int tiles[PER][4];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) tiles[k][j] = -1;
+        if (pix[k] != 0xffffffffu) {
+            pcl_bin_tiles((int)(pix[k] >> 16), (int)(pix[k] & 0xffffu), a.H, a.W, a.ntx, a.ty_lo, a.ty_hi, tiles[k]);
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (tiles[k][j] >= 0) atomicAdd(&cnt[tiles[k][j]], 1);
@@ -584,9 +624,21 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
         me = hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
         if (me != hipSuccess) return (int)me;
         dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
-        hipLaunchKernelGGL(pcl_bin_kernel<false>, pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-        hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-        hipLaunchKernelGGL(pcl_bin_kernel<true>, pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+        const size_t win_bytes = 0;      // (the LDS-window form of the dedup lived here)
+        // pre-dedup pays where pixels hold several points: measured at 1M points on 2048 x 1024 (0.5 points per pixel) resolve 613 ->
+        // 498, scatter 491 -> 437, count 283 -> 355 us per 64 candidates (-7 % for the stage); at 167k points (0.08 per pixel)
+        // nothing is dropped and the compares cost 9 us per 50 candidates — hence the density gate.  PCL_BIN_DEDUP=0 / 1 forces.
+        const int dedup_env = pcl_hist_env_int("PCL_BIN_DEDUP", -1);
+        const bool dedup = dedup_env >= 0 ? dedup_env != 0 : 4 * n >= (int64_t)H * W;
+        if (dedup) {
+            hipLaunchKernelGGL((pcl_bin_kernel<false, true>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int) + win_bytes, s, b);
+            hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+            hipLaunchKernelGGL((pcl_bin_kernel<true, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int) + win_bytes, s, b);
+        } else {
+            hipLaunchKernelGGL((pcl_bin_kernel<false, false>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+            hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+            hipLaunchKernelGGL((pcl_bin_kernel<true, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+        }
         hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel, dim3(ncand, nt), dim3(PCL_RESOLVE_THREADS), 0, s, b, img_hwc, nsh, nsw, ghist_c);
     } else {
         hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
