@@ -131,6 +131,16 @@ typedef struct pcl_gd_hyper {
     int32_t depth_mask; /* 0 = reference behaviour; 1 = recompute the scatter-min depth mask (pcl_depth_mask) for the
                            current poses before every loss pass (build-defined, cfg key `depth_mask`) */
     float depth_tau;    /* visibility tolerance of the depth mask */
+    float depth_refresh_t; /* with depth_mask: candidate b's mask is recomputed before a loss pass only when its forward pose differs  */
+    float depth_refresh_r; /* from the pose the mask in use was computed for by MORE than depth_refresh_t (metres) in a translation     */
+                           /* component or depth_refresh_r (radians) in yaw / pitch / roll.  0 / 0 (default): whenever the pose moved  */
+                           /* at all, i.e. the mask is always that of the current pose (an unmoved pose has an unchanged mask).        */
+                           /* Otherwise the mask in use is at most that stale: a point at distance d has moved in the panorama by at    */
+                           /* most (depth_refresh_t / d + depth_refresh_r) * W / (2 pi) pixels per component since its mask was made.  */
+                           /* Build-defined like the mask itself (no reference call site).                                             */
+    int32_t depth_every;   /* and only when the mask in use has served at least depth_every loss passes (0 or 1: no such condition).   */
+                           /* depth_every = k with bounds 0 / 0: the mask is recomputed at every k-th iteration, i.e. it is at most    */
+                           /* k - 1 Adam steps old (<= (k - 1) * lr per parameter).                                                    */
 } pcl_gd_hyper;
 
 size_t pcl_gd_state_bytes(int B);
@@ -141,6 +151,8 @@ int pcl_gd_run(const float *cloud, int64_t n, const void *pano, int pano_format,
                const pcl_gd_hyper *hyper_host, int num_iter, float *loss_history, void *workspace,
                size_t workspace_bytes, void *timer, void *stream);
 int pcl_gd_result(const void *state, int B, float *result, void *stream);
+/* counts [B] (device, int32): how many times each candidate's depth mask has been computed since pcl_gd_init (0 without depth_mask) */
+int pcl_gd_depth_refresh_counts(const void *state, int B, int *counts, void *stream);
 /* How pcl_gd_run decomposes an n-point, B-candidate problem (host-only query, measurement aid): chunks of the cloud, poses per
  * block, and whether an iteration is ONE launch (the loss launch of iteration k + 1 finishes iteration k in the prologue of every
  * block: launches whose chunk x group blocks are all resident at once — the reference's shipped 167k-point / 6-candidate shape)

@@ -20,7 +20,8 @@ PANO_F32, PANO_U8, PANO_F16 = 0, 1, 2
 
 class GdHyper(_c.Structure):
     _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32),
-                ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float)]
+                ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float), ("depth_refresh_t", _c.c_float), ("depth_refresh_r", _c.c_float),
+                ("depth_every", _c.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/piccolo_hip.h declares
@@ -74,6 +75,7 @@ SIGNATURES = {
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
     "pcl_timer_calibrate": (_int, [_vp, _int, _c.POINTER(_dbl), _vp]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
+    "pcl_gd_depth_refresh_counts": (_int, [_vp, _int, _vp, _vp]),
     "pcl_gd_plan": (_int, [_i64, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
     "pcl_gd_set_pano_groups": (_int, [_vp, _c.POINTER(_c.c_uint64), _int, _int, _vp]),

@@ -24,6 +24,8 @@ struct PclDepthArgs {
     float tol2;           // (1 + tau)^2
     uint32_t* zbuf;       // [B][H*W]
     uint8_t* visible;     // [B][n]
+    const uint32_t* refresh;   // null, or: pose b is processed only when refresh[b * refresh_stride] != 0 (its mask is kept otherwise)
+    int refresh_stride;        // in 32-bit words
 };
 
 // make_pano's pixel (utils.py:158-165) from the fused kernel's own atan2, plus the squared depth
@@ -52,6 +54,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_depth_kernel(PclDepthArgs a)
 {
     // grid.x over points, grid.y over poses; pose record through scalar loads
     const int b = blockIdx.y;
+    if (a.refresh && !a.refresh[(int64_t)b * a.refresh_stride]) return;
     const PclPoseRec* __restrict__ pr = a.poses + b;
     const int64_t hw = (int64_t)a.H * a.W;
     for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * PCL_BLOCK) {
@@ -78,6 +81,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_zpass_tiled_kernel(PclDepthArgs
     __shared__ uint32_t tile[PCL_ZT_H * PCL_ZT_W];
     __shared__ int org[3];
     const int b = blockIdx.y;
+    if (a.refresh && !a.refresh[(int64_t)b * a.refresh_stride]) return;            // (block-uniform, before the first barrier)
     const PclPoseRec* __restrict__ pr = a.poses + b;
     uint32_t* __restrict__ zb = a.zbuf + (int64_t)b * a.H * a.W;
     const uint32_t INF = 0x7f800000u;
@@ -130,24 +134,28 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_zpass_tiled_kernel(PclDepthArgs
     }
 }
 
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u32_kernel(uint32_t* p, int64_t n, uint32_t v)
+// z-buffer of pose blockIdx.y <- v (skipped for poses whose mask is kept)
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u32_kernel(uint32_t* p, int64_t per_pose, uint32_t v, const uint32_t* __restrict__ refresh,
+                                                                 int refresh_stride)
 {
-    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = v;
+    if (refresh && !refresh[(int64_t)blockIdx.y * refresh_stride]) return;
+    uint32_t* q = p + (int64_t)blockIdx.y * per_pose;
+    for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < per_pose; i += (int64_t)gridDim.x * PCL_BLOCK) q[i] = v;
 }
 
 size_t pcl_depth_zbuf_bytes(int B, int H, int W) { return (size_t)B * (size_t)H * (size_t)W * sizeof(uint32_t); }
 
 // zbuf: pcl_depth_zbuf_bytes; visible: B * n bytes.  Used by pcl_depth_mask and by the GD loop (pcl_gd.hip).
 int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
-                          uint32_t* zbuf, uint8_t* visible, hipStream_t s)
+                          uint32_t* zbuf, uint8_t* visible, const uint32_t* refresh, int refresh_stride, hipStream_t s)
 {
     PclDepthArgs a;
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.poses = poses; a.B = B; a.H = H; a.W = W;
     a.tol2 = (1.0f + tau) * (1.0f + tau);
-    a.zbuf = zbuf; a.visible = visible;
-    int64_t cells = (int64_t)B * H * W;
-    hipLaunchKernelGGL(pcl_fill_u32_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, cells, 0x7f800000u);   // +inf
+    a.zbuf = zbuf; a.visible = visible; a.refresh = refresh; a.refresh_stride = refresh_stride;
+    const int fill_x = B >= 32 ? 64 : (2048 + B - 1) / B;
+    hipLaunchKernelGGL(pcl_fill_u32_kernel, dim3((unsigned)fill_x, (unsigned)B), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)H * W, 0x7f800000u, refresh, refresh_stride);   // +inf
     int64_t want = (n + PCL_BLOCK - 1) / PCL_BLOCK;
     dim3 grid((unsigned)(want < 1024 ? want : 1024), (unsigned)B);
     static const bool direct = getenv("PCL_ZPASS_DIRECT") != nullptr;       // A/B knob: the untiled scatter
@@ -189,5 +197,5 @@ extern "C" int pcl_depth_mask(const float* cloud, int64_t n, const float* trans,
     PclPoseRec* recs = (PclPoseRec*)workspace;
     uint32_t* zbuf = (uint32_t*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
     hipLaunchKernelGGL(pcl_depth_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
-    return pcl_launch_depth_mask(cloud, n, recs, B, H, W, tau, zbuf, visible, s);
+    return pcl_launch_depth_mask(cloud, n, recs, B, H, W, tau, zbuf, visible, nullptr, 1, s);
 }

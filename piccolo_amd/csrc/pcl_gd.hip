@@ -19,7 +19,7 @@ int pcl_plan_nblocks(int64_t n, int B);
 int pcl_plan_G(int64_t n, int B);
 size_t pcl_depth_zbuf_bytes(int B, int H, int W);
 int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
-                          uint32_t* zbuf, uint8_t* visible, hipStream_t s);
+                          uint32_t* zbuf, uint8_t* visible, const uint32_t* refresh, int refresh_stride, hipStream_t s);
 
 // ---------------------------------------------------------------- stateless loss: pose setup + finish
 
@@ -98,6 +98,57 @@ static inline PclPoseRec* gd_recs(void* state, int B, int copy = 0)
     return (PclPoseRec*)((char*)state + (size_t)copy * gd_copy_bytes(B) + (size_t)B * sizeof(PclGdPose));
 }
 
+// Depth-mask refresh record of a candidate (behind the two state copies): the forward pose its current mask was computed for, the
+// flag the depth passes of this iteration read, and how many times the mask has been computed.
+struct PclDepthSnap {
+    float pose[6];
+    uint32_t refresh, count, age, pad[3];      // age: loss passes the mask in use has served
+};
+static_assert(sizeof(PclDepthSnap) == 48, "depth refresh record");
+static inline PclDepthSnap* gd_snaps(void* state, int B) { return (PclDepthSnap*)((char*)state + 2 * gd_copy_bytes(B)); }
+
+// refresh[b] = the mask in use has served at least `every` loss passes AND the forward pose of candidate b moved by more than
+// thr_t in a translation component or thr_r in an angle since that mask was computed (always true for a fresh state: the
+// snapshot starts as NaN).  Thresholds of 0: whenever it moved at all — an unmoved pose has an unchanged mask, so with every = 1
+// that is exactly "the current pose's mask at every iteration".
+__global__ void pcl_depth_refresh_kernel(const PclGdPose* __restrict__ st, PclDepthSnap* snaps, int B, float thr_t, float thr_r, int every)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    PclDepthSnap sn = snaps[b];
+    bool moved = false;
+    for (int k = 0; k < 6; k++) {
+        const float d = fabsf(st[b].fwd[k] - sn.pose[k]);
+        moved = moved || !(d <= (k < 3 ? thr_t : thr_r));            // (NaN snapshot: not <=, so moved)
+    }
+    const bool fresh = sn.pose[0] != sn.pose[0];
+    const bool go = moved && (fresh || sn.age >= (uint32_t)every);
+    sn.refresh = go ? 1u : 0u;
+    if (go) {
+        for (int k = 0; k < 6; k++) sn.pose[k] = st[b].fwd[k];
+        sn.count += 1u;
+        sn.age = 0u;
+    }
+    sn.age += 1u;
+    snaps[b] = sn;
+}
+
+__global__ void pcl_depth_snap_init_kernel(PclDepthSnap* snaps, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    PclDepthSnap sn;
+    for (int k = 0; k < 6; k++) sn.pose[k] = __builtin_nanf("");
+    sn.refresh = 1u; sn.count = 0u; sn.age = 0u; sn.pad[0] = sn.pad[1] = sn.pad[2] = 0u;
+    snaps[b] = sn;
+}
+
+__global__ void pcl_depth_snap_count_kernel(const PclDepthSnap* __restrict__ snaps, int B, int* __restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = (int)snaps[b].count;
+}
+
 __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, PclPoseRec* recs_shadow, const float* __restrict__ trans,
                                    const float* __restrict__ rot, int B, double lr)
 {
@@ -139,7 +190,7 @@ __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, fl
     r[13] = (float)st[b].lr;
 }
 
-extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? 2 * gd_copy_bytes(B) : 0; }
+extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? 2 * gd_copy_bytes(B) + (size_t)B * sizeof(PclDepthSnap) : 0; }
 
 static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -156,6 +207,8 @@ extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, in
     if (!state || !trans || !rot || !hyper_host || B <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_poses(state),
                        gd_recs(state, B), gd_recs(state, B, 1), trans, rot, B, hyper_host->lr);
+    if (hyper_host->depth_mask)
+        hipLaunchKernelGGL(pcl_depth_snap_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_snaps(state, B), B);
     PCL_LAUNCH_CHECK();
     return 0;
 }
@@ -275,6 +328,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     uint8_t* visible = nullptr;
     if (hyper_host->depth_mask) {
         if (!(hyper_host->depth_tau >= 0.f) || B > 65535) return PCL_EINVAL;
+        if (!(hyper_host->depth_refresh_t >= 0.f) || !(hyper_host->depth_refresh_r >= 0.f) || hyper_host->depth_every < 0) return PCL_EINVAL;
         zbuf = (uint32_t*)((char*)workspace + 2 * gd_align(pcl_partials_bytes(n, B)));
         visible = (uint8_t*)zbuf + gd_align(pcl_depth_zbuf_bytes(B, H, W));
     }
@@ -306,7 +360,13 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     };
     for (int it = 0; it < num_iter; it++) {
         if (visible) {
-            int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, s);
+            // which candidates need a new mask: those whose forward pose left the refresh bound around the pose their mask
+            // was computed for; the depth passes of the others return at once (their z-buffer and byte mask stay)
+            PclDepthSnap* snaps = gd_snaps(state, B);
+            hipLaunchKernelGGL(pcl_depth_refresh_kernel, dim3((B + 255) / 256), dim3(256), 0, s, gd_poses(state, B, 0), snaps, B,
+                               hyper_host->depth_refresh_t, hyper_host->depth_refresh_r, hyper_host->depth_every > 1 ? hyper_host->depth_every : 1);
+            int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, &snaps->refresh,
+                                            (int)(sizeof(PclDepthSnap) / sizeof(uint32_t)), s);
             if (rcd) return rcd;
         }
         // time every `stride`-th launch only: an event pair costs a few microseconds of GPU timeline, which would
@@ -435,6 +495,15 @@ extern "C" int pcl_gd_winner(const void* state, int nimages, int per_image, floa
     if (!state || !winners || nimages <= 0 || per_image <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_winner_kernel, dim3((nimages + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const PclGdPose*)state, nimages,
                        per_image, winners, leaf_trans, leaf_rot);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcl_gd_depth_refresh_counts(const void* state, int B, int* counts, void* stream)
+{
+    if (!state || !counts || B <= 0) return PCL_EINVAL;
+    hipLaunchKernelGGL(pcl_depth_snap_count_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const PclDepthSnap*)gd_snaps((void*)state, B), B, counts);
     PCL_LAUNCH_CHECK();
     return 0;
 }

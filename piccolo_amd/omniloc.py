@@ -12,8 +12,11 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     localize.py:227 on numpy >= 2);
   * omniloc_batch also accepts a single candidate (the reference asserts num_input > 1, omniloc.py:208; the assert
     is kept because callers may rely on it, see `strict_reference_asserts`);
-  * two extra, optional cfg keys: depth_mask (default False = reference behaviour) multiplies the north star's
-    scatter-min visibility (csrc/pcl_depth.hip) into the loss mask, depth_tau is its tolerance;
+  * extra, optional cfg keys: depth_mask (default False = reference behaviour) multiplies the north star's
+    scatter-min visibility (csrc/pcl_depth.hip) into the loss mask, depth_tau is its tolerance; depth_refresh_t (metres) /
+    depth_refresh_r (radians), default 0: a candidate's mask is recomputed only when its forward pose has left that bound
+    around the pose the mask in use was computed for (0: always the current pose's mask; include/piccolo_hip.h states the bound);
+    depth_every = k (default 1): and only when the mask in use has served k loss passes (every k-th iteration with bounds 0);
   * cfg.visualize: the reference's frame capture is broken (`new_xyz` undefined, omniloc.py:61 -> NameError); here
     omniloc returns the frame list that code means to build (query image over the cloud rendered at the current pose,
     per iteration) as 4th element.
@@ -155,7 +158,8 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
     num_iter = _cfg(cfg, "num_iter", 100)
     depth = bool(_cfg(cfg, "depth_mask", False))
     hyper = (float(_cfg(cfg, "lr", 0.1)), int(_cfg(cfg, "patience", 5)), float(_cfg(cfg, "factor", 0.9)), bool(batch_mode), depth,
-             float(_cfg(cfg, "depth_tau", 0.02)))
+             float(_cfg(cfg, "depth_tau", 0.02)), float(_cfg(cfg, "depth_refresh_t", 0.0)), float(_cfg(cfg, "depth_refresh_r", 0.0)),
+             int(_cfg(cfg, "depth_every", 1)))
     use_graph = _cfg(cfg, "gd_graph", None)
     if use_graph is None and os.environ.get("PCL_GD_GRAPH") in ("0", "1"):          # experiments
         use_graph = os.environ["PCL_GD_GRAPH"] == "1"
@@ -165,7 +169,7 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
 
     def make(c=cloud, bx=box):
         return ops.GradientDescent(c, p0, trans, rot, bx, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
-                                   depth_mask=hyper[4], depth_tau=hyper[5])
+                                   depth_mask=hyper[4], depth_tau=hyper[5], depth_refresh_t=hyper[6], depth_refresh_r=hyper[7], depth_every=hyper[8])
     if not use_graph:
         gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
     else:

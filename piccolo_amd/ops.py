@@ -391,14 +391,14 @@ class GradientDescent:
     """On-device GD refinement of B candidates (Adam + ReduceLROnPlateau + clamp), pcl_gd_* of the C ABI."""
 
     def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True, depth_mask=False,
-                 depth_tau=0.02):
+                 depth_tau=0.02, depth_refresh_t=0.0, depth_refresh_r=0.0, depth_every=1):
         lib = _lib.load()
         self.cloud, self.pano = cloud, pano
         trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
         self.B = int(trans.shape[0])
         self.box = _dev(box).reshape(6)
         self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL,
-                                  1 if depth_mask else 0, float(depth_tau))
+                                  1 if depth_mask else 0, float(depth_tau), float(depth_refresh_t), float(depth_refresh_r), int(depth_every))
         self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
         self.ws_bytes = lib.pcl_gd_workspace_bytes(cloud.n, self.B, pano.H, pano.W, ctypes.byref(self.hyper))
         self.ws = _bytes(self.ws_bytes)
@@ -487,6 +487,13 @@ class GradientDescent:
                 raise ValueError("winner: leaf buffers must be contiguous float32 GPU tensors of B x 3")
         _lib.check(lib.pcl_gd_winner(_ptr(self.state), nimages, self.B // nimages, _ptr(out), _ptr(leaf_trans), _ptr(leaf_rot), _stream()),
                    "pcl_gd_winner")
+        return out
+
+    def depth_refresh_counts(self):
+        """(B,) int32 GPU tensor: how many times each candidate's depth mask has been computed since the last init / reset."""
+        out = torch.zeros(self.B, dtype=torch.int32, device=self.state.device)
+        if self.hyper.depth_mask:
+            _lib.check(_lib.load().pcl_gd_depth_refresh_counts(_ptr(self.state), self.B, _ptr(out), _stream()), "pcl_gd_depth_refresh_counts")
         return out
 
     def result(self):

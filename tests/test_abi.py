@@ -60,7 +60,8 @@ def test_size_queries_and_argument_checks(lib):
     assert lib.pcl_cloud_bytes(1000) == 1024 * 6 * 4
     assert lib.pcl_pano_bytes(4, 8, _lib.PANO_F32) == 6 * 10 * 16 and lib.pcl_pano_bytes(4, 8, _lib.PANO_U8) == 6 * 10 * 4 and lib.pcl_pano_bytes(4, 8, _lib.PANO_F16) == 6 * 10 * 8
     assert lib.pcl_pano_bytes(4, 8, 7) == 0 and lib.pcl_pano_bytes(0, 8, 0) == 0
-    assert lib.pcl_gd_state_bytes(32) == 2 * 32 * (160 + 64)        # two copies: fused iterations read one while they write the other
+    # two copies (fused iterations read one while they write the other) + the 48-byte depth-mask refresh record per candidate
+    assert lib.pcl_gd_state_bytes(32) == 2 * 32 * (160 + 64) + 32 * 48
     ws1, ws2 = lib.pcl_loss_workspace_bytes(1_000_000, 32), lib.pcl_loss_workspace_bytes(1_000_000, 256)
     assert 0 < ws1 < ws2 < 64 << 20
     assert lib.pcl_loss_workspace_bytes(0, 32) == 0

@@ -721,6 +721,59 @@ def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
     assert not torch.equal(r_on[0], r_off[0])            # the mask changed the objective
 
 
+def test_depth_mask_refresh_bound(ops):
+    """cfg depth_refresh_t / depth_refresh_r (build-defined, include/piccolo_hip.h): a candidate's depth mask is recomputed only
+    when its forward pose has left the bound around the pose the mask in use was computed for.  Bounds of 0 = the mask of the
+    current pose at every iteration (round 3's behaviour: the same bits); huge bounds = the starting pose's mask throughout (one
+    computation per candidate); a small bound recomputes while the pose still moves and stops as the steps shrink, and lands where
+    the every-iteration run lands."""
+    from piccolo_amd import synth
+    n, H, W, B, tau = 40_000, 128, 256, 4, 0.02
+    xyz, rgb = synth.box_room(n, 17)
+    inner, inner_rgb = synth.box_room(n // 4, 18)
+    xyz = np.concatenate([xyz, inner * 0.25 + np.array([1.5, 1.0, 0.0], np.float32)]).astype(np.float32)
+    rgb = np.concatenate([rgb, inner_rgb]).astype(np.float32)
+    t_gt, ypr_gt = synth.gt_pose(17)
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=17, sigma_t=0.1, sigma_r=0.05)
+    X, C = T(xyz), T(rgb)
+    cloud = ops.Cloud(X, C)
+    img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, T(t_gt), T(ypr_gt)), C, (H, W)))
+    pano, box = ops.Pano(img), ops.quantile_box(X, 0.05)
+
+    def run(n_it, **kw):
+        gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True, depth_mask=True,
+                                 depth_tau=tau, **kw)
+        gd.run(n_it)
+        return gd.result().cpu().numpy(), gd.depth_refresh_counts().cpu().numpy()
+
+    every, c_every = run(60)
+    again, _ = run(60, depth_refresh_t=0.0, depth_refresh_r=0.0)
+    assert np.array_equal(every, again) and (c_every >= 55).all() and (c_every <= 60).all()     # (a pose that did not move keeps its mask)
+    once, c_once = run(60, depth_refresh_t=1e9, depth_refresh_r=1e9)
+    assert (c_once == 1).all() and not np.array_equal(once, every)
+    # Adam's steps are ~lr per parameter until the scheduler has cut lr: a bound that skips anything is a visible one
+    some, c_some = run(60, depth_refresh_t=2e-2, depth_refresh_r=2e-2)
+    assert (c_some < c_every).all() and (c_some >= 3).all(), (c_some, c_every)
+    # depth_every = 4 with bounds 0: every fourth iteration (15 masks in 60 iterations while the pose moves)
+    fourth, c_fourth = run(60, depth_every=4)
+    assert (c_fourth <= 15).all() and (c_fourth >= 13).all(), c_fourth
+    R_gt = synth.rot_from_ypr_np(ypr_gt)
+    for res in (every, some, fourth):
+        k = int(np.argmin(res[:, 12]))
+        e = synth.pose_errors(res[k, :3], ops.rot_from_ypr(T(res[k:k + 1, 3:6]))[0].cpu().numpy(), t_gt, R_gt)
+        assert e[0] < 0.05 and e[1] < 1.0, e
+    assert np.abs(some[:, :3] - every[:, :3]).max() < 0.05
+    # run() in pieces keeps the records; reset() starts them afresh
+    gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True, depth_mask=True,
+                             depth_tau=tau, depth_refresh_t=2e-2, depth_refresh_r=2e-2)
+    gd.run(25); gd.run(35)
+    assert np.array_equal(gd.result().cpu().numpy(), some) and np.array_equal(gd.depth_refresh_counts().cpu().numpy(), c_some)
+    gd.reset(T(trans), T(rot))
+    assert (gd.depth_refresh_counts().cpu().numpy() == 0).all()
+    with pytest.raises(Exception):
+        ops.GradientDescent(cloud, pano, T(trans), T(rot), box, depth_mask=True, depth_refresh_t=-1.0).run(1)
+
+
 def test_gd_graph_replay_is_bit_identical(ops):
     """pcl_gd_run captured into a hipGraph and replayed == the eager launch sequence, bit for bit (deterministic
     two-stage reduction, no atomics on the path)."""
