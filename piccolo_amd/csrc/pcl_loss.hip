@@ -139,6 +139,14 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
         // Projection and sampling phase per pose.  (Measured: projecting all poses of the group before sampling the
         // first — gathers of pose g in flight under the projection of pose g+1 — changes nothing at 4 waves/SIMD and
         // costs 30 VGPRs; the kernel is VALU-issue bound, not latency bound.)
+#ifndef PCL_NO_ROTATE_PAIR
+        f2 rot_p[G][3];
+        if constexpr (G == 2) {
+            if constexpr (FUSED) pcl_rotate2x2(x, y, z, P6[0], P6[1], rot_p[0][0], rot_p[0][1], rot_p[0][2], rot_p[1][0], rot_p[1][1], rot_p[1][2]);
+            else pcl_rotate2x2(x, y, z, pcl_pose6(a.poses + pose0), pcl_pose6(a.poses + pose0 + 1), rot_p[0][0], rot_p[0][1], rot_p[0][2],
+                               rot_p[1][0], rot_p[1][1], rot_p[1][2]);
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const PclPoseRec* __restrict__ pr = a.poses + (pose0 + g);
@@ -165,6 +173,12 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
+#ifndef PCL_NO_ROTATE_PAIR
+            if constexpr (G == 2) {
+                pj.px = rot_p[g][0]; pj.py = rot_p[g][1]; pj.pz = rot_p[g][2];
+                pcl_project2_rotated<FMT>(tg, a.dims, pj);
+            } else
+#endif
             if constexpr (FUSED) pcl_project2<FMT>(x, y, z, P6[g], tg, a.dims, pj);
             else pcl_project2<FMT>(x, y, z, pcl_pose6(pr), tg, a.dims, pj);
             pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tg, a.dims, acc[g], count[g]);

@@ -570,7 +570,7 @@ def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
                     gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
                     gd.set_panos(table)
                     hist = gd.run(num_iter, history=True)
-                    runs.append((hist.clone(), gd.result().clone(), gd.state.clone()[: gd.state.numel() // 2]))
+                    runs.append((hist.clone(), gd.result().clone(), gd.state.clone()[: B * (160 + 64)]))
                 # in pieces: 2 + 1 + 4 iterations continue one another exactly like 7 in one call
                 gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
                 gd.set_panos(table)
@@ -579,12 +579,12 @@ def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
                 gd7.set_panos(table)
                 whole = gd7.run(7, history=True)
                 assert torch.equal(pieces, whole) and torch.equal(gd.result(), gd7.result()), (n, B, mode)
-                runs.append((pieces.clone(), gd.result().clone(), gd.state.clone()[: gd.state.numel() // 2]))
+                runs.append((pieces.clone(), gd.result().clone(), gd.state.clone()[: B * (160 + 64)]))
                 out[mode] = runs
             for (h2, r2, s2), (hf, rf, sf) in zip(out["two"], out["fused"]):
                 assert torch.equal(h2, hf), (n, B, "loss history", (h2 - hf).abs().max())
                 assert torch.equal(r2, rf), (n, B, "result")
-                assert torch.equal(s2, sf), (n, B, "optimiser state")          # (canonical copy of the state blob, byte for byte)
+                assert torch.equal(s2, sf), (n, B, "optimiser state")          # (canonical copy of the state blob — B x (160 B state + 64 B pose record) — byte for byte)
     finally:
         if old is None:
             os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
