@@ -158,6 +158,8 @@ int pcl_gd_depth_refresh_counts(const void *state, int B, int *counts, void *str
  * block: launches whose chunk x group blocks are all resident at once — the reference's shipped 167k-point / 6-candidate shape)
  * or two (loss + epilogue).  Any of the three outputs may be NULL. */
 int pcl_gd_plan(int64_t n, int B, int *nchunks_host, int *poses_per_block_host, int *fused_host);
+/* the same for the hyper-parameters a run will use: a depth-masked run (hyper->depth_mask) never fuses; hyper NULL = pcl_gd_plan */
+int pcl_gd_plan_hyper(int64_t n, int B, const pcl_gd_hyper *hyper_host, int *nchunks_host, int *poses_per_block_host, int *fused_host);
 /* Several query images against one shared cloud in ONE launch chain (BASELINE cfg 4: independent panoramas, shared
  * cloud): candidate b samples panos[b] (device array of B device addresses of packed panoramas; all the same H, W and
  * texel format as the `pano` passed to pcl_gd_run, which stays the default for entries that are 0).  Call after

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
     "pcl_gd_depth_refresh_counts": (_int, [_vp, _int, _vp, _vp]),
     "pcl_gd_plan": (_int, [_i64, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
+    "pcl_gd_plan_hyper": (_int, [_i64, _int, _c.POINTER(GdHyper), _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),
     "pcl_gd_set_pano_groups": (_int, [_vp, _c.POINTER(_c.c_uint64), _int, _int, _vp]),
     "pcl_gd_winner": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp]),

@@ -272,13 +272,20 @@ static int gd_fuse_limit()
     return fuse_env && *fuse_env ? atoi(fuse_env) : 1024;
 }
 
-extern "C" int pcl_gd_plan(int64_t n, int B, int* nchunks_host, int* poses_per_block_host, int* fused_host)
+extern "C" int pcl_gd_plan_hyper(int64_t n, int B, const pcl_gd_hyper* hyper_host, int* nchunks_host, int* poses_per_block_host, int* fused_host)
 {
     if (n <= 0 || n > PCL_MAX_POINTS || B <= 0) return PCL_EINVAL;
     if (nchunks_host) *nchunks_host = pcl_plan_nchunks(n, B);
     if (poses_per_block_host) *poses_per_block_host = pcl_plan_G(n, B);
-    if (fused_host) *fused_host = pcl_plan_nblocks(n, B) <= gd_fuse_limit() ? 1 : 0;
+    // (the depth-masked loss pass reads a byte mask the fused prologue knows nothing about: pcl_gd_run keeps two launches there)
+    const bool depth = hyper_host && hyper_host->depth_mask;
+    if (fused_host) *fused_host = (!depth && pcl_plan_nblocks(n, B) <= gd_fuse_limit()) ? 1 : 0;
     return 0;
+}
+
+extern "C" int pcl_gd_plan(int64_t n, int B, int* nchunks_host, int* poses_per_block_host, int* fused_host)
+{
+    return pcl_gd_plan_hyper(n, B, nullptr, nchunks_host, poses_per_block_host, fused_host);
 }
 
 extern "C" int pcl_timer_calibrate(void* timer, int reps, double* pair_ms_host, void* stream)

@@ -100,9 +100,12 @@ def test_sampling_loss_golden(ops, parity, sort, fmt):
     out = _loss(ops, g["xyz"], g["rgb"], g["img"], g["trans"], g["rot"], sort=sort, fmt=fmt)
     gap_l = rel(g["loss_f32"], g["loss_f64"])
     gap_t, gap_r = rel(g["grad_t_f32"], g["grad_t_f64"]), rel(g["grad_ypr_f32"], g["grad_ypr_f64"])
-    parity("loss vs ref fp64", rel(out[:, 0], g["loss_f64"]), 3e-7, gap_l)
+    # per-component bounds = the measured value + a third (round 3 had widened grad_t AND grad_ypr to one 2e-6 when the
+    # half-angle elevation doubled the grad_t error 7.0e-7 -> 1.40e-6; the components that did not regress keep their margin, so
+    # that a further drift of any of them is caught): loss 6e-8 ... 1.04e-7 -> 1.5e-7, grad_ypr 5.0e-7 ... 5.75e-7 -> 7e-7, grad_t 1.46e-6 -> 2e-6
+    parity("loss vs ref fp64", rel(out[:, 0], g["loss_f64"]), 1.5e-7, gap_l)
     parity("grad_t vs ref fp64", rel(out[:, 2:5], g["grad_t_f64"]), 2e-6, gap_t)
-    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 2e-6, gap_r)
+    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 7e-7, gap_r)
     assert 2e-6 < gap_t and 2e-6 < gap_r                   # (the bound really is below the reference's own fp32 gap)
     # against the reference's fp32 run the distance is that run's own error
     parity("grad_t vs ref fp32", rel(out[:, 2:5], g["grad_t_f32"]), 1.5 * gap_t, gap_t)
@@ -113,10 +116,11 @@ def test_batch_sampling_loss_golden(ops, parity):
     """G4 (BatchSamplingLoss, B = 4, reference autograd): bounds as for G3 (reference fp32: 2.7e-7 / 3.4e-6 / 2.7e-6)."""
     s, g = load_golden("g3_sampling_loss.npz"), load_golden("g4_batch_sampling_loss.npz")
     out = _loss(ops, s["xyz"], s["rgb"], s["img"], g["trans"], g["rot"])
-    parity("loss_list vs ref fp64", rel(out[:, 0], g["loss_list_f64"]), 3e-7, rel(g["loss_list_f32"], g["loss_list_f64"]))
+    # (measured 8.9e-8 / 6.4e-7 / 6.6e-7: per-component bounds at measured + a third)
+    parity("loss_list vs ref fp64", rel(out[:, 0], g["loss_list_f64"]), 1.2e-7, rel(g["loss_list_f32"], g["loss_list_f64"]))
     parity("sum(loss_list) vs ref fp64 (abs)", abs(out[:, 0].astype(np.float64).sum() - g["loss_f64"]), 5e-7)
-    parity("grad_t vs ref fp64", rel(out[:, 2:5], g["grad_t_f64"]), 2e-6, rel(g["grad_t_f32"], g["grad_t_f64"]))
-    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 2e-6, rel(g["grad_ypr_f32"], g["grad_ypr_f64"]))
+    parity("grad_t vs ref fp64", rel(out[:, 2:5], g["grad_t_f64"]), 9e-7, rel(g["grad_t_f32"], g["grad_t_f64"]))
+    parity("grad_ypr vs ref fp64", rel(out[:, 5:8], g["grad_ypr_f64"]), 9e-7, rel(g["grad_ypr_f32"], g["grad_ypr_f64"]))
 
 
 def test_pano_format_selection_and_float_image(ops, oracle, parity):

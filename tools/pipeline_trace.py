@@ -55,18 +55,20 @@ from piccolo_amd import omniloc as po, utils, synth  # noqa: E402
 
 n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 166_667
+NUM_INPUT = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+NUM_INTER = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 sc = bench.Scene(N, 1024, 2048, torch.device("cuda:0"))
 
 
 class Cfg:
-    lr, num_iter, patience, factor, out_of_room_quantile, num_input = 0.1, 100, 5, 0.8, 0.05, 6
+    lr, num_iter, patience, factor, out_of_room_quantile, num_input = 0.1, 100, 5, 0.8, 0.05, NUM_INPUT
 
 
 for j in range(n_images):
     e = sc.image(2_000_000 + j, keep_img=True)
     img = e["img"]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    tr, ro = utils.make_input(img, sc.X, sc.C, 6, bench.STANFORD_INIT, "loss_histogram", 50)
+    tr, ro = utils.make_input(img, sc.X, sc.C, NUM_INPUT, bench.STANFORD_INIT, "loss_histogram", NUM_INTER)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     res = po.omniloc_batch(img, sc.X, sc.C, tr, ro, Cfg(), {})
     torch.cuda.synchronize(); t2 = time.perf_counter()
