@@ -285,7 +285,8 @@ class Scene:
             t_gt, ypr_gt = synth.gt_pose(image_id)
             cam = ops.transform_cloud(self.X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt))
             img = synth.quantise_like_image_file(ops.make_pano(cam, self.C, (self.H, self.W)))   # uint8-quantised like a decoded image file
-            e = {"pano": ops.Pano(img), "gt": (t_gt, ypr_gt)}
+            # (the texel format the product's refinement takes for this cloud / panorama: fp16 levels, RGBA8 for sparse clouds)
+            e = {"pano": ops.Pano(img, fmt=ops.refine_texels(self.N, self.H, self.W)), "gt": (t_gt, ypr_gt)}
             if keep_img:
                 e["img"] = img
             self._img[image_id] = e

@@ -38,7 +38,7 @@ strict_reference_asserts = True
 # cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
 # An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
 # references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
-_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 4, "gd": 6, "trimgroups": 4}
+_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 16, "gd": 6, "trimgroups": 4}
 
 
 class _PackCache:
@@ -112,12 +112,17 @@ def packed_cloud(xyz, rgb):
     return _cached("cloud", (xyz, rgb), make)
 
 
-def packed_pano(img, many_poses=False):
-    """Packed panorama of `img`, cached per tensor.  `many_poses`: the launch evaluates hundreds of candidate poses all
-    over the room (trim_input_loss): RGBA8 texels then, half the footprint of the fp16-level default — with 1800 poses
-    the fp16 texture thrashes L2 (8.7 vs 5.3 ms per launch at cfg-2 size), while the refinement's few nearby poses run
-    5 % faster on it.  Images that are not k/255 get float4 texels either way."""
-    if not many_poses:
+def packed_pano(img, many_poses=False, n_points=None):
+    """Packed panorama of `img`, cached per tensor.  RGBA8 texels (half the footprint of the fp16-level default) when the launch
+    evaluates hundreds of candidate poses all over the room (`many_poses`, trim_input_loss: with 1800 poses the fp16 texture
+    thrashes L2, 8.7 vs 5.3 ms per launch at cfg-2 size) or when the cloud to be refined is sparse against the panorama
+    (`n_points`: ops.refine_texels — the refinement then shares the trim stage's packing of the image); fp16-level texels
+    otherwise (the refinement's nearby poses on a dense cloud run 5 % faster on them).  Images that are not k/255 get float4
+    texels either way."""
+    rgba8 = many_poses or (n_points is not None and ops.refine_texels(n_points, img.shape[0], img.shape[1]) == "u8")
+    if os.environ.get("PCL_PANO_FMT") in ("f16", "f32") and not many_poses:      # experiments: force the refinement's format
+        rgba8 = False
+    if not rgba8:
         return _cached("pano", (img,), lambda: ops.Pano(img))
 
     def make():
@@ -231,7 +236,7 @@ def omniloc(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, scalar_s
     vis = _cfg(cfg, "visualize", False)
     out_quantile = _cfg(cfg, "out_of_room_quantile", 0.05)
 
-    pano = packed_pano(img)
+    pano = packed_pano(img, n_points=xyz.shape[0])
     # the reference recomputes these three quantiles every iteration (omniloc.py:53-55); they are loop invariant
     box = quantile_box_of(xyz, out_quantile)
     frames = []
@@ -280,7 +285,7 @@ def omniloc_all(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries=Non
     Every starting point keeps omniloc's SEQUENTIAL semantics (its own Adam / scheduler, clamp applied to the parameters
     the next forward reads) and the points never interact, so the list returned equals the K separate calls."""
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
-    res = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, False).result()
+    res = _refine(xyz, rgb, [packed_pano(img, n_points=xyz.shape[0])], input_trans, input_rot, box, cfg, False).result()
     K = res.shape[0]
     R = ops.rot_from_ypr(res[:, 3:6])
     host = torch.cat([res[:, 0:3], R.reshape(K, 9), res[:, 12:13]], dim=1).cpu()
@@ -297,7 +302,7 @@ def omniloc_batch(img, xyz, rgb, input_trans, input_rot, cfg, scalar_summaries):
     if strict_reference_asserts:
         assert cfg.num_input > 1
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))
-    gd = _refine(xyz, rgb, [packed_pano(img)], input_trans, input_rot, box, cfg, True)
+    gd = _refine(xyz, rgb, [packed_pano(img, n_points=xyz.shape[0])], input_trans, input_rot, box, cfg, True)
     # loss_list.argmin() of the last forward, R of the winner and the write-back of the leaves: one kernel, then the one D2H copy
     # of the whole refinement (64 bytes)
     bt, br, after = _leaf_buffers(input_trans, input_rot, gd.B)
@@ -319,7 +324,8 @@ def omniloc_batch_images(imgs, xyz, rgb, input_trans_list, input_rot_list, cfg, 
         assert cfg.num_input > 1
     I = len(imgs)
     B = int(input_trans_list[0].shape[0])
-    panos = [packed_pano(im) if I <= 8 else ops.Pano(im) for im in imgs]
+    fmt = ops.refine_texels(xyz.shape[0], imgs[0].shape[0], imgs[0].shape[1])
+    panos = [packed_pano(im, n_points=xyz.shape[0]) if I <= 8 else ops.Pano(im, fmt=fmt if ops._known_levels(im) else "auto") for im in imgs]
     if len({p.fmt for p in panos}) > 1:          # a launch needs ONE texel format: float4 holds any image
         panos = [ops.Pano(im, fmt="f32") for im in imgs]
     box = quantile_box_of(xyz, _cfg(cfg, "out_of_room_quantile", 0.05))

@@ -10,9 +10,9 @@ ROOF_KEY=cfg5/poses64/f16 POINT_POSES=640e6 ROOF_SOURCE=$R/c2_cfg5_2images ROOF_
   bash profiles/collect.sh ${R}_c --workload cfg5 --steps 4 --warmup 1 --no-cpu-baseline
 ROOF_KEY=cfg3/poses256/f16 POINT_POSES=256e6 ROOF_SOURCE=$R/d_cfg3 ROOF_CMD="bench.py --workload cfg3 --steps 2" \
   bash profiles/collect.sh ${R}_d --workload cfg3 --steps 2 --warmup 1 --no-cpu-baseline
-ROOF_KEY=shipped/poses6/f16 POINT_POSES=1000002 ROOF_SOURCE=$R/h_shipped_1image ROOF_CMD="bench.py --workload shipped --images-per-launch 1" \
+ROOF_KEY=shipped/poses6/u8 POINT_POSES=1000002 ROOF_SOURCE=$R/h_shipped_1image ROOF_CMD="bench.py --workload shipped --images-per-launch 1" \
   bash profiles/collect.sh ${R}_h --workload shipped --images-per-launch 1 $PMC
-ROOF_KEY=shipped/poses48/f16 POINT_POSES=8000016 ROOF_SOURCE=$R/i_shipped_8images ROOF_CMD="bench.py --workload shipped --images-per-launch 8" \
+ROOF_KEY=shipped/poses48/u8 POINT_POSES=8000016 ROOF_SOURCE=$R/i_shipped_8images ROOF_CMD="bench.py --workload shipped --images-per-launch 8" \
   bash profiles/collect.sh ${R}_i --workload shipped --images-per-launch 8 $PMC
 bash profiles/collect.sh ${R}_e --script tools/init_bench.py
 bash profiles/collect.sh ${R}_f --script tools/chain_bench.py 167000 6 1

@@ -7,6 +7,11 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from piccolo_amd import ops, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 166_667
+if N < 0:                  # sweep of the spread modes in one process: python tools/iter_latency.py -166667 6
+    import subprocess
+    for sp in (0, 1, 2, 3):
+        subprocess.run([sys.executable, __file__, str(-N)] + sys.argv[2:3] + ["10", str(sp)])
+    sys.exit(0)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 spread = int(sys.argv[4]) if len(sys.argv) > 4 else 1
@@ -22,6 +27,12 @@ if spread:
     tr = (t_gt[None] + rng.normal(0, 1.0, size=(B, 3))).astype(np.float32)
     ro = (rng.integers(0, 4, size=(B, 3)) * (np.pi / 2)).astype(np.float32)
     tr[0], ro[0] = t_gt + 0.2, ypr_gt + 0.1
+    if spread == 2:        # the candidates of a pose group (G = 2: rows 2k, 2k + 1) look the same way from nearby places
+        for k in range(0, B - 1, 2):
+            ro[k + 1] = ro[k]; tr[k + 1] = tr[k] + np.float32(0.2)
+    if spread == 3:        # pairs share the translation, rotations differ
+        for k in range(0, B - 1, 2):
+            tr[k + 1] = tr[k]
 cloud, pano, box = ops.Cloud(X, C), ops.Pano(img), ops.quantile_box(X, 0.05)
 gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev), box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
 gd.run_graph(100); torch.cuda.synchronize()
