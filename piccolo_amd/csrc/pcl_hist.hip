@@ -310,7 +310,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_scan_kernel(PclBinArgs a)
 // the pixels where the query image is not black into the block histograms (LDS for the up to 2 x 2 histogram blocks a tile
 // overlaps; tiny blocks — more than that per tile — go to the global counters directly).
 // (1024 threads: the heaviest tile of a candidate — up to 20x the mean — sets the duration of the launch)
-#define PCL_RESOLVE_THREADS 1024
+// (1024 threads: the heaviest tile of a candidate — up to 20x the mean — sets the duration of the launch.  Round 4 tried 256-thread
+//  workgroups for sparse clouds, eight resident per CU instead of two: slower at every shape, PCL_RESOLVE_THREADS=256 keeps the A/B)
 #ifdef PCL_BLOCK_TRACE                                 // experiments: tools/block_trace.py-style end stamps (see pcl_loss.hip)
 __device__ unsigned long long* pcl_hist_trace_buf = nullptr;
 extern "C" int pcl_debug_set_hist_trace(unsigned long long* buf)
@@ -318,6 +319,7 @@ extern "C" int pcl_debug_set_hist_trace(unsigned long long* buf)
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(pcl_hist_trace_buf), &buf, sizeof(buf));
 }
 #endif
+template <int PCL_RESOLVE_THREADS>
 __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, const float* __restrict__ img, int nsh, int nsw,
                                                                           unsigned int* __restrict__ ghist)
 {
@@ -639,7 +641,10 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
             hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
             hipLaunchKernelGGL((pcl_bin_kernel<true, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
         }
-        hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel, dim3(ncand, nt), dim3(PCL_RESOLVE_THREADS), 0, s, b, img_hwc, nsh, nsw, ghist_c);
+        const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
+        const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
+        if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, img_hwc, nsh, nsw, ghist_c);
+        else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, img_hwc, nsh, nsw, ghist_c);
     } else {
         hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
         // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
