@@ -69,6 +69,11 @@ const char *pcl_source_hash(void);
 #define PCL_PANO_F32 0
 #define PCL_PANO_U8 1
 #define PCL_PANO_F16 2
+/* PCL_PANO_U8P: RGBA8 with the ROWS INTERLEAVED IN PAIRS — element (x, k) = 8 bytes = texel (x, 2k), texel (x, 2k + 1) of the bordered
+ * image, element rows of W + 2 elements.  A 2 x 2 footprint that starts on an even row is ONE 16-byte access, on an odd row two:
+ * 1.5 texture accesses per sample on average instead of 2, with the memory of PCL_PANO_U8.  Only the forward-only trim launch takes
+ * it (pcl_trim_loss / pcl_trim_loss_images: bound by the texture unit's line rate); pcl_pano_pack_u8p packs it. */
+#define PCL_PANO_U8P 3
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
@@ -82,6 +87,7 @@ int pcl_morton_keys(const float *xyz, int64_t n, const float *lo_host, const flo
 size_t pcl_pano_bytes(int H, int W, int pano_format);
 int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream);
 int pcl_pano_pack_u8(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
+int pcl_pano_pack_u8p(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
 int pcl_pano_pack_f16(const float *img_hwc, int H, int W, void *pano, int *not_exact, void *stream);
 
 /* ---- sampling loss (+ gradient) ----------------------------------------------------------------------------

@@ -15,7 +15,7 @@ ABI_VERSION = 6
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 14
 GD_SEQUENTIAL, GD_BATCH = 0, 1
-PANO_F32, PANO_U8, PANO_F16 = 0, 1, 2
+PANO_F32, PANO_U8, PANO_F16, PANO_U8P = 0, 1, 2, 3
 
 
 class GdHyper(_c.Structure):
@@ -38,6 +38,7 @@ SIGNATURES = {
     "pcl_cloud_order_workspace_bytes": (_sz, [_i64]),
     "pcl_cloud_order": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "pcl_pano_pack_u8": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
+    "pcl_pano_pack_u8p": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_pano_pack_f16": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
     "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),

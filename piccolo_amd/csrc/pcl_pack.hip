@@ -26,7 +26,9 @@ extern "C" int64_t pcl_cloud_stride(int64_t n) { return n <= 0 ? 0 : ((n + 255) 
 extern "C" size_t pcl_cloud_bytes(int64_t n) { return (size_t)pcl_cloud_stride(n) * 6 * sizeof(float); }
 extern "C" size_t pcl_pano_bytes(int H, int W, int pano_format)
 {
-    if (H <= 0 || W <= 0 || (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16)) return 0;
+    if (H <= 0 || W <= 0) return 0;
+    if (pano_format == PCL_PANO_U8P) return (size_t)((H + 3) >> 1) * (size_t)(W + 2) * 8;       // element rows of row PAIRS
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return 0;
     return (size_t)(H + 2) * (size_t)(W + 2) * (size_t)pcl_texel_bytes(pano_format);
 }
 
@@ -232,6 +234,30 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8_kernel(const float
     pano[i] = v;
 }
 
+// RGBA8 with the rows interleaved in pairs (PCL_PANO_U8P): the texel of bordered row yp, column xp goes to 32-bit word
+// ((yp >> 1) * Wp + xp) * 2 + (yp & 1).  One thread per word of the padded layout (an odd H + 2 leaves a last half-pair: zeros).
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8p_kernel(const float* __restrict__ img, int H, int W,
+                                                                      uint32_t* __restrict__ pano, int* __restrict__ not_exact)
+{
+    const int Wp = W + 2, pairs = (H + 3) >> 1;
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= (int64_t)Wp * pairs * 2) return;
+    const int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+    uint32_t v = 0u;
+    if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
+        const float* s = img + ((int64_t)(yp - 1) * W + (xp - 1)) * 3;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float f = s[c], k = rintf(f * 255.f);
+            bad = bad || !(k >= 0.f && k <= 255.f) || __fdiv_rn(k, 255.f) != f;
+            v |= ((uint32_t)k & 255u) << (8 * c);
+        }
+        if (bad) *not_exact = 1;
+    }
+    pano[((int64_t)(yp >> 1) * Wp + xp) * 2 + (yp & 1)] = v;
+}
+
 // half4 texels holding the levels 0..255 as fp16 (exact), for the same k/255 images as RGBA8.
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_f16_kernel(const float* __restrict__ img, int H, int W,
                                                                       pcl_i2* __restrict__ pano, int* __restrict__ not_exact)
@@ -263,6 +289,16 @@ extern "C" int pcl_pano_pack_f16(const float* img_hwc, int H, int W, void* pano,
     int64_t total = (int64_t)(H + 2) * (W + 2);
     hipLaunchKernelGGL(pcl_pano_pack_f16_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
                        (hipStream_t)stream, img_hwc, H, W, (pcl_i2*)pano, not_exact);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pcl_pano_pack_u8p(const float* img_hwc, int H, int W, uint32_t* pano, int* not_exact, void* stream)
+{
+    if (!img_hwc || !pano || !not_exact || H <= 0 || W <= 0) return PCL_EINVAL;
+    int64_t total = (int64_t)((H + 3) >> 1) * 2 * (W + 2);
+    hipLaunchKernelGGL(pcl_pano_pack_u8p_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, img_hwc, H, W, pano, not_exact);
     PCL_LAUNCH_CHECK();
     return 0;
 }

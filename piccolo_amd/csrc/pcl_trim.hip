@@ -203,25 +203,48 @@ struct PclTrimArgs {
 
 #define PCL_STEP (2 * PCL_BLOCK)
 
-// gathers of one point for the panorama row offset `row` (texels) and column x0
+// PCL_PANO_U8P (include/piccolo_hip.h): RGBA8 with the rows interleaved in pairs.  Round 4: the launch is bound by the texture unit's
+// line rate (one L1 line lookup per cycle per CU, TA busy 0.80 at 167k points, profiles/r04/t_trim_167k_*), and with row-major
+// texels every sample costs two accesses (its two rows).  Here the footprint of a sample that starts on an EVEN row is one 16-byte
+// access, on an odd row two (issued for the odd lanes only): 1.5 accesses per sample, the same texture bytes.  (Round 3's vertical
+// PAIRS — every texel stored with the one below it, one access per sample but twice the texture — lost at the sparse shape: 1.05 ->
+// 1.25 ms, the 16.8 MB no longer lived in the L2s.)  The four dwords are sorted into the RGBA8 sampler's (top pair, bottom pair):
+// the same texels, the same arithmetic, tables bit-identical to PCL_PANO_U8's.
+template <> struct PclTaps<PCL_PANO_U8P> { pcl_i4 a, b; };
+
+// gathers of one point for the panorama row offset `row` (texels; U8P: element-row offset (y0 >> 1) * Wp) and column x0
 template <int FMT>
-__device__ __forceinline__ void pcl_issue_taps_row(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<FMT>& o);
+__device__ __forceinline__ void pcl_issue_taps_row(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool odd, PclTaps<FMT>& o);
 template <>
-__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<PCL_PANO_U8>& o)
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8P>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool odd, PclTaps<PCL_PANO_U8P>& o)
+{
+    const int voff = (row + x0) * 8;
+    o.a = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0);                    // elements (x0, k), (x0 + 1, k): rows 2k, 2k + 1
+    if (odd) o.b = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0);      // the footprint's second row lives in element row k + 1
+}
+__device__ __forceinline__ PclTaps<PCL_PANO_U8> pcl_taps_u8_of(const PclTaps<PCL_PANO_U8P>& p, bool odd)
+{
+    PclTaps<PCL_PANO_U8> t;
+    t.top = (pcl_i2){odd ? p.a.y : p.a.x, odd ? p.a.w : p.a.z};
+    t.bot = (pcl_i2){odd ? p.b.x : p.a.y, odd ? p.b.z : p.a.w};
+    return t;
+}
+template <>
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool, PclTaps<PCL_PANO_U8>& o)
 {
     int voff = (row + x0) * 4;
     o.top = pcl_texel_pair_u8(tex, voff, 0);
     o.bot = pcl_texel_pair_u8(tex, voff, Wp * 4);
 }
 template <>
-__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F16>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, PclTaps<PCL_PANO_F16>& o)
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F16>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool, PclTaps<PCL_PANO_F16>& o)
 {
     int voff = (row + x0) * 8;
     o.top = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, 0, 0);
     o.bot = __builtin_amdgcn_raw_buffer_load_b128(tex, voff, Wp * 8, 0);
 }
 template <>
-__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F32>(__amdgpu_buffer_rsrc_t, int row, int x0, int Wp, PclTaps<PCL_PANO_F32>& o)
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_F32>(__amdgpu_buffer_rsrc_t, int row, int x0, int Wp, bool, PclTaps<PCL_PANO_F32>& o)
 {
     o.voff = (row + x0) * 16;
     o.row = Wp * 16;
@@ -249,7 +272,9 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
     const int ny = gr->ny;
     const PclPoseRec* __restrict__ pose = a.poses + slot;
 
-    __amdgpu_buffer_rsrc_t tex = pcl_tex_rsrc(a.pano[image], a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
+    __amdgpu_buffer_rsrc_t tex = FMT == PCL_PANO_U8P
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)a.pano[image], 0, (int)((size_t)((a.dims.H + 3) >> 1) * (size_t)a.dims.Wp * 8), 0x00020000)
+        : pcl_tex_rsrc(a.pano[image], a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
     const int plane = (int)a.stride * 4;
 
@@ -291,7 +316,10 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
         const float lim_el = 0.495f * 3.14159265358979323846f;
         f2 elc = {__builtin_amdgcn_fmed3f(elev.x, -lim_el, lim_el), __builtin_amdgcn_fmed3f(elev.y, -lim_el, lim_el)};
         f2 iy = pcl_fma2(elc, F2(a.dims.k_iy), F2(a.dims.off_y));
-        const int row0 = (int)__umul24((unsigned)(int)iy.x, (unsigned)a.dims.Wp), row1 = (int)__umul24((unsigned)(int)iy.y, (unsigned)a.dims.Wp);
+        const int y0a = (int)iy.x, y0b = (int)iy.y;
+        const bool odd0 = FMT == PCL_PANO_U8P && (y0a & 1), odd1 = FMT == PCL_PANO_U8P && (y0b & 1);
+        const int row0 = (int)__umul24((unsigned)(FMT == PCL_PANO_U8P ? y0a >> 1 : y0a), (unsigned)a.dims.Wp);
+        const int row1 = (int)__umul24((unsigned)(FMT == PCL_PANO_U8P ? y0b >> 1 : y0b), (unsigned)a.dims.Wp);
         const f2 fy = {__builtin_amdgcn_fractf(iy.x), __builtin_amdgcn_fractf(iy.y)};
         // The column in turns, counted the way the image runs: f = 0.5 - phi / 2 pi in [0, 1] <-> phi in [-pi, pi]; g = f - 0.5.
         // -phi0 / 2 pi, and the first-order carry of the reference's p_x + 1e-6:  d phi = -eps p_y / rho^2
@@ -336,13 +364,21 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
             pj[yy].px = pj[yy].py = pj[yy].pz = F2(0.f);                    // (read only by the gradient variant of the sampler)
             pj[yy].fx = (f2){__builtin_amdgcn_fractf(ix.x), __builtin_amdgcn_fractf(ix.y)};
             pj[yy].fy = fy;
-            pcl_issue_taps_row<FMT>(tex, row0, (int)ix.x, a.dims.Wp, pj[yy].ta);
-            pcl_issue_taps_row<FMT>(tex, row1, (int)ix.y, a.dims.Wp, pj[yy].tb);
+            pcl_issue_taps_row<FMT>(tex, row0, (int)ix.x, a.dims.Wp, odd0, pj[yy].ta);
+            pcl_issue_taps_row<FMT>(tex, row1, (int)ix.y, a.dims.Wp, odd1, pj[yy].tb);
         }
 #pragma unroll
         for (int yy = 0; yy < PCL_TRIM_Y; yy++) {
             if (yy >= ny) break;
-            pcl_sample2<false, FMT>(pj[yy], ncr, ncg, ncb, valid0, valid1, vmask0, vmask1, tex, a.dims, acc[yy], count[yy]);
+            if constexpr (FMT == PCL_PANO_U8P) {
+                PclProj<PCL_PANO_U8> q;
+                q.px = q.py = q.pz = F2(0.f);
+                q.fx = pj[yy].fx; q.fy = pj[yy].fy;
+                q.ta = pcl_taps_u8_of(pj[yy].ta, odd0);
+                q.tb = pcl_taps_u8_of(pj[yy].tb, odd1);
+                pcl_sample2<false, PCL_PANO_U8>(q, ncr, ncg, ncb, valid0, valid1, vmask0, vmask1, tex, a.dims, acc[yy], count[yy]);
+            } else
+                pcl_sample2<false, FMT>(pj[yy], ncr, ncg, ncb, valid0, valid1, vmask0, vmask1, tex, a.dims, acc[yy], count[yy]);
         }
     };
     float bufA[2][6], bufB[2][6];
@@ -417,8 +453,8 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
     for (int i = 0; i < nimages; i++)
         if (!panos_host[i]) return PCL_EINVAL;
     if (n <= 0 || n > PCL_MAX_POINTS || K <= 0 || R <= 0 || ngroups <= 0 || ngroups > R || H <= 0 || W <= 0) return PCL_EINVAL;
-    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
-    if ((int64_t)(H + 2) * (W + 2) * pcl_texel_bytes(pano_format) >= ((int64_t)1 << 31)) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16 && pano_format != PCL_PANO_U8P) return PCL_EINVAL;
+    if ((int64_t)(H + 3) * (W + 2) * (pano_format == PCL_PANO_U8P ? 4 : pcl_texel_bytes(pano_format)) >= ((int64_t)1 << 31)) return PCL_EINVAL;
     if ((int64_t)ngroups * K * nimages > (1 << 24)) return PCL_EINVAL;
     if (workspace_bytes < trim_workspace_bytes(n, K, ngroups, nimages)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -437,13 +473,14 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     for (int i = 0; i < PCL_TRIM_MAX_IMAGES; i++) a.pano[i] = i < nimages ? panos_host[i] : nullptr;
     a.nimages = nimages;
-    a.dims = pcl_make_dims(H, W, pano_format);
+    a.dims = pcl_make_dims(H, W, pano_format == PCL_PANO_U8P ? PCL_PANO_U8 : pano_format);       // (the same levels, the same constants)
     a.poses = recs; a.hdr = hdr; a.groups = grs; a.K = K; a.nslots = nslots; a.partials = partials;
     // the chunks of the SINGLE-image launch, whatever the number of images: per-image tables keep that launch's bits
     pcl_plan_for_groups(n, nslots, &a.nchunks, &a.seg_len, &a.steps_base, &a.steps_rem);
     const int64_t nblk = (int64_t)a.nchunks * nslots * nimages;
     if (nblk > 0x7fffffffll) return PCL_EINVAL;
-    if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    if (pano_format == PCL_PANO_U8P) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8P>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    else if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_F16) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F16>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F32>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     hipLaunchKernelGGL(pcl_trim_finish_kernel, dim3((nimages * nslots * PCL_TRIM_Y + 255) / 256), dim3(256), 0, s, partials, a.nchunks, nslots,

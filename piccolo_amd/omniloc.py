@@ -38,7 +38,7 @@ strict_reference_asserts = True
 # cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
 # An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
 # references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
-_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 16, "gd": 6, "trimgroups": 4}
+_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 16, "pano_u8p": 16, "gd": 6, "trimgroups": 4}
 
 
 class _PackCache:
@@ -124,13 +124,17 @@ def packed_pano(img, many_poses=False, n_points=None):
         rgba8 = False
     if not rgba8:
         return _cached("pano", (img,), lambda: ops.Pano(img))
+    # the trim launch of a sparse cloud takes the rows interleaved in pairs (ops.trim_texels); nothing else reads that layout
+    fmt = "u8p" if many_poses and n_points is not None and ops.trim_texels(n_points, img.shape[0], img.shape[1]) == "u8p" else "u8"
+    if os.environ.get("PCL_TRIM_FMT") in ("u8", "u8p") and many_poses:            # experiments
+        fmt = os.environ["PCL_TRIM_FMT"]
 
     def make():
         try:
-            return ops.Pano(img, fmt="u8")
+            return ops.Pano(img, fmt=fmt)
         except ValueError:
             return ops.Pano(img, fmt="f32")
-    return _cached("pano_u8", (img,), make)
+    return _cached("pano_" + fmt, (img,), make)
 
 
 def _cfg(cfg, key, default):

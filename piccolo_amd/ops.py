@@ -87,7 +87,8 @@ class Pano:
     same k/255 images as RGBA8 (4 B/texel: half the footprint, ~5 % slower loss kernel), "f32" forces float4.  The
     exactness test is one kernel and one 4-byte D2H read per image, outside the GD loop."""
 
-    _PACK = {"f16": ("pcl_pano_pack_f16", _lib.PANO_F16), "u8": ("pcl_pano_pack_u8", _lib.PANO_U8)}
+    _PACK = {"f16": ("pcl_pano_pack_f16", _lib.PANO_F16), "u8": ("pcl_pano_pack_u8", _lib.PANO_U8),
+             "u8p": ("pcl_pano_pack_u8p", _lib.PANO_U8P)}         # u8p: rows interleaved in pairs, for the trim launch only
 
     def __init__(self, img, fmt="auto"):
         lib = _lib.load()
@@ -97,7 +98,7 @@ class Pano:
             raise ValueError("img must be (H, W, 3)")
         self.H, self.W = int(img.shape[0]), int(img.shape[1])
         self.fmt = None
-        if fmt not in ("auto", "f16", "u8", "f32"):
+        if fmt not in ("auto", "f16", "u8", "u8p", "f32"):
             raise ValueError("unknown texel format %r" % (fmt,))
         prefer = "f16"
         if fmt == "auto":                                     # experiments: PCL_PANO_FMT = what "auto" tries first
@@ -130,6 +131,14 @@ def refine_texels(n, H, W):
     400k points 24.1 -> 19.8 us; at 1M points the two are within 2.5 % of each other either way (tools/iter_latency.py).  The
     formats give the same bits (tests/test_hip_parity.py::test_pano_format_selection_and_float_image)."""
     return "u8" if 2 * int(n) < int(H) * int(W) else "f16"
+
+
+def trim_texels(n, H, W):
+    """Level-texel format ("u8" | "u8p") for the TRIM launch of an n-point cloud against an H x W panorama: rows interleaved in pairs
+    (1.5 texture accesses per sample instead of 2, same bytes) where the launch is bound by the texture unit's line rate — measured
+    167k points 1.05 -> 0.87 ms, 400k 1.77 -> 1.53 ms per 1800-pose launch on 2048 x 1024, bit-identical tables — and plain rows
+    where it is VALU-bound (1M points: 3.3 ms either way, the four selects per sample cost what the saved accesses buy)."""
+    return "u8p" if 3 * int(n) < int(H) * int(W) else "u8"
 
 
 def _known_levels(img):

@@ -173,7 +173,9 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     roll grid (utils.py:321-360), and for R = RZ(yaw) RY RX neither the panorama row nor the distance depends on yaw."""
     from .omniloc import _cached
     K, Rn = len(trans), len(rot)
-    cloud, pano = packed_cloud(xyz, rgb), packed_pano(img, many_poses=True)
+    cloud = packed_cloud(xyz, rgb)
+    # (the generic kernel of the R > 1024 fallback reads row-major texels only)
+    pano = packed_pano(img, many_poses=True, n_points=xyz.shape[0] if Rn <= ops.TRIM_MAX_ROT else None)
     # the (pitch, roll) classes of the rotation table: once per table (the grid is cached per config in make_input)
     if Rn <= ops.TRIM_MAX_ROT:
         groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot)) if torch.is_tensor(rot) else ops.TrimGroups(rot)
@@ -346,7 +348,7 @@ def make_input_images(imgs, xyz, rgb, num_input, init_dict=None, criterion="hist
     if I == 1 or Rn > ops.TRIM_MAX_ROT or n_mid > ops.SELECT_MAX_KEEP:
         return [make_input(im, xyz, rgb, num_input, init_dict, criterion, num_intermediate) for im in imgs]
     cloud = packed_cloud(xyz, rgb)
-    panos = [packed_pano(im, many_poses=True) for im in imgs]
+    panos = [packed_pano(im, many_poses=True, n_points=xyz.shape[0]) for im in imgs]
     if len({p.fmt for p in panos}) > 1:                       # a launch needs one texel format: float4 holds any image
         panos = [ops.Pano(im, fmt="f32") for im in imgs]
     groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot))

@@ -266,6 +266,21 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
         flips = max(dcount, float(np.abs(count.reshape(-1) - gen[:, 1]).max())) + nseam
         parity(name + ": loss table vs the generic forward kernel", rel(table.reshape(-1), gen[:, 0]), 3e-7 + 2.0 * flips / n)
         parity(name + ": loss table vs fp64 oracle", rel(table.reshape(-1), ref["loss"]), 3e-7 + 2.0 * flips / n, rel(gen[:, 0], ref["loss"]))
+    # RGBA8 with the rows interleaved in pairs (PCL_PANO_U8P, the trim launch's format for sparse clouds): the same texels through
+    # one 16-byte access (even rows) or two (odd rows) — tables and counts bit-identical to row-major RGBA8, for every grid shape,
+    # also on a panorama with an odd number of rows (a last half pair) and for several images per launch
+    for name, rot, tr, _ in cases[:4]:
+        groups = ops.TrimGroups(T(rot))
+        t8, c8 = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(tr), groups, return_count=True)
+        tp, cp = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8p"), T(tr), groups, return_count=True)
+        assert torch.equal(torch.nan_to_num(t8, nan=-1.0), torch.nan_to_num(tp, nan=-1.0)) and torch.equal(c8, cp), name
+    img_odd = img[:-1].contiguous()                       # 127 rows
+    groups = ops.TrimGroups(T(stanford))
+    t8 = ops.trim_loss_table(cloud, ops.Pano(img_odd, fmt="u8"), T(trans), groups)
+    tp = ops.trim_loss_tables(cloud, [ops.Pano(img_odd, fmt="u8p"), ops.Pano(img_odd, fmt="u8p")], T(trans), groups)
+    assert torch.equal(t8, tp[0]) and torch.equal(t8, tp[1])
+    with pytest.raises(Exception):                         # nothing but the trim launch reads that layout
+        ops.sampling_loss(cloud, ops.Pano(img, fmt="u8p"), T(trans[:2]), T(stanford[:2]))
     # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once
     groups = ops.TrimGroups(T(stanford))
     want = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Trim launch with row-major RGBA8 texels vs rows interleaved in pairs (PCL_PANO_U8P): tables must agree bit for bit; ms per launch.
+   python tools/trim_u8p.py [n_points ...]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from piccolo_amd import ops, synth, utils
+H, W = 1024, 2048
+dev = torch.device("cuda:0")
+for n in [int(a) for a in sys.argv[1:]] or [166_667, 1_000_000]:
+    xyz, rgb = synth.box_room(n, 0)
+    X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+    t_gt, ypr_gt = synth.gt_pose(3)
+    img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
+    rot = utils.generate_rot_points(bench.STANFORD_INIT, device=dev)
+    trans = utils.generate_trans_points(X, bench.STANFORD_INIT, device=dev)
+    groups, cloud = ops.TrimGroups(rot), ops.Cloud(X, C)
+    out = {}
+    for fmt in ("u8", "u8p", "u8", "u8p"):
+        pano = ops.Pano(img, fmt=fmt)
+        t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize()
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter(); t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        out.setdefault(fmt, []).append(float(np.median(ts)))
+        out[fmt + "_table"] = t
+    print("n %d: u8 %s ms | u8p %s ms | tables equal: %s (NaN-aware), max abs diff %.3e" % (
+        n, out["u8"], out["u8p"], bool(torch.equal(torch.nan_to_num(out["u8_table"], nan=-1.0), torch.nan_to_num(out["u8p_table"], nan=-1.0))),
+        float((out["u8_table"] - out["u8p_table"]).abs().nan_to_num().max())))
