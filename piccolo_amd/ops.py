@@ -125,12 +125,13 @@ class Pano:
 def refine_texels(n, H, W):
     """Level-texel format ("f16" | "u8") for the REFINEMENT of an n-point cloud against an H x W panorama.  fp16-level texels (8 B)
     save 6 VALU instructions per point-pose and win where the loss kernel is VALU-bound (cfg 2: +4-5 %); a sparse cloud — fewer than
-    one point per two pixels — is bound by texture lines and latency instead (the 2 x 2 footprints of a wave's 128 Morton neighbours
+    one point per three pixels — is bound by texture lines and latency instead (the 2 x 2 footprints of a wave's 128 Morton neighbours
     share no cache line), and RGBA8 texels (4 B: half the texture in L2) win: measured per GD iteration with the starting poses
     make_input hands over, 167k points on 2048 x 1024: 6 candidates 14.1 -> 12.0 us, 48 candidates (8 images per chain) 70.5 -> 45.4 us;
-    400k points 24.1 -> 19.8 us; at 1M points the two are within 2.5 % of each other either way (tools/iter_latency.py).  The
+    400k points 24.1 -> 19.8 us; at 1M points (0.48 points per pixel: cfg 2, which stays on fp16 levels) the two are within 2.5 % of each
+    other, fp16 ahead for poses near each other, RGBA8 for poses all over the room (tools/iter_latency.py).  The
     formats give the same bits (tests/test_hip_parity.py::test_pano_format_selection_and_float_image)."""
-    return "u8" if 2 * int(n) < int(H) * int(W) else "f16"
+    return "u8" if 3 * int(n) < int(H) * int(W) else "f16"
 
 
 def trim_texels(n, H, W):
