@@ -11,7 +11,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from piccolo_amd import _lib, ops, synth, utils  # noqa: E402
 
-n, H, W = 1_000_000, 1024, 2048
+n, H, W = (int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000), 1024, 2048
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = torch.device("cuda:0")
 xyz, rgb = synth.box_room(n, 0)
 X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
@@ -22,11 +23,11 @@ init = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_
             z_min=None, num_split_h=4, num_split_w=4, xy_only=False, num_trans=50, yaw_only=False, num_yaw=4, num_pitch=4,
             num_roll=4, dataset="Stanford2D-3D-S")
 rot, trans = utils.generate_rot_points(init, device=dev), utils.generate_trans_points(X, init, device=dev)
-t1, r1 = utils.trim_input_loss(img, X, C, trans, rot, 16)
+t1, r1 = utils.trim_input_loss(img, X, C, trans, rot, NC)
 cloud = ops.Cloud(X, C)
 raw = ctypes.CDLL(_lib.so_path())
 nt = (H // 64) * (W // 64)
-buf = torch.zeros(16 * nt * 5, dtype=torch.int64, device=dev)
+buf = torch.zeros(NC * nt * 5, dtype=torch.int64, device=dev)
 raw.pcl_debug_set_hist_trace.argtypes = [ctypes.c_void_p]
 ops.hist_trim_scores(img, cloud, t1, r1, 4, 4)
 assert raw.pcl_debug_set_hist_trace(ctypes.c_void_p(buf.data_ptr())) == 0
