@@ -44,9 +44,10 @@ for fmt in fmts:
         groups = ops.TrimGroups(rot)
         tt, rr = trans.repeat(R, 1), rot.repeat_interleave(K, dim=0)          # rotation-major, as the generic path launched it
         shared = timed(lambda: ops.trim_loss_table(cloud, pano, trans, groups))
-        generic = timed(lambda: ops.sampling_loss(cloud, pano, tt, rr, with_grad=False))
+        gpano = pano if fmt != "u8p" else ops.Pano(img, fmt="u8")           # (the generic kernel reads row-major texels only)
+        generic = timed(lambda: ops.sampling_loss(cloud, gpano, tt, rr, with_grad=False))
         a = ops.trim_loss_table(cloud, pano, trans, groups).reshape(-1)
-        b = ops.sampling_loss(cloud, pano, tt, rr, with_grad=False)[:, 0].reshape(R, K).t().reshape(-1)
+        b = ops.sampling_loss(cloud, gpano, tt, rr, with_grad=False)[:, 0].reshape(R, K).t().reshape(-1)
         print("%s %s: %d x %d pairs in %d groups | yaw-shared %.2f ms | generic %.2f ms | %.2fx | max rel diff %.1e | same top-64: %s" % (
             fmt, name, K, R, groups.ngroups, shared, generic, generic / shared, float((a - b).abs().max() / b.abs().max()),
             bool(set(torch.topk(a, 64, largest=False).indices.tolist()) == set(torch.topk(b, 64, largest=False).indices.tolist()))))
