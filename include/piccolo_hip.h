@@ -252,6 +252,17 @@ int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, in
  * up to its first empty block (utils.py:568-571), divided by nsh * nsw (utils.py:580). */
 int pcl_hist_trim_reduce(const float *inter, const int32_t *nproj, const int32_t *nimg, int ncand, int nsh, int nsw, float *score,
                          void *stream);
+/* The same for `nimages` query images of ONE room in one set of launches (<= 32 images): candidates [i * cand_per_image,
+ * (i + 1) * cand_per_image) of trans / rot are rendered and scored against imgs_host[i] (HOST array of device addresses of (H, W, 3)
+ * float images); inter / nproj [nimages * cand_per_image][nblk], nimg [nimages][nblk], score [nimages * cand_per_image].  Every image's
+ * candidates form their own chain of the empty-block carry-over (one call of the reference's function per image); results are
+ * those of the single-image entry points, bit for bit. */
+size_t pcl_hist_trim_images_workspace_bytes(int64_t n, int nimages, int cand_per_image, int H, int W, int nsh, int nsw);
+int pcl_hist_trim_scores_images(const float *cloud, int64_t n, const float *const *imgs_host, int nimages, int cand_per_image, int H, int W,
+                                const float *trans, const float *rot, int nsh, int nsw, float *inter, int32_t *nproj, int32_t *nimg,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int pcl_hist_trim_reduce_images(const float *inter, const int32_t *nproj, const int32_t *nimg, int nimages, int cand_per_image, int nsh,
+                                int nsw, float *score, void *stream);
 /* First trimming stage of the initialisation, utils.py:462-507 trim_input_loss: the forward-only sampling loss
  * (utils.py:484-499 = omniloc.py:171-202 without gradient) of ALL K x R pairs of trans [K][3] and rot [R][3] (yaw, pitch, roll),
  * loss_table [K][R] row-major like the reference's `loss_table[i, j]` (utils.py:497; its argsort / index decode stay with the

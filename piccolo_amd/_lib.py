@@ -59,6 +59,9 @@ SIGNATURES = {
     "pcl_cloud_txt_rows": (_i64, [_c.c_char_p]),
     "pcl_cloud_txt_read": (_i64, [_c.c_char_p, _i64, _int, _vp, _int]),
     "pcl_hist_trim_reduce": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp]),
+    "pcl_hist_trim_images_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int, _int]),
+    "pcl_hist_trim_scores_images": (_int, [_vp, _i64, _c.POINTER(_vp), _int, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_hist_trim_reduce_images": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
     "pcl_trim_groups_bytes": (_sz, [_int]),
     "pcl_trim_groups": (_int, [_vp, _int, _vp, _vp]),
     "pcl_trim_loss_workspace_bytes": (_sz, [_i64, _int, _int]),

@@ -120,6 +120,11 @@ __device__ inline int pcl_hist_code(float r, float g, float b)
 #define PCL_TS 64                      // tile edge in pixels
 #define PCL_TS_SHIFT 6
 
+// Several query images of one room in one set of launches (round 4): candidate c is scored against image c / cpi.  The float
+// images' addresses travel as kernel arguments.
+#define PCL_HIST_MAX_IMAGES 32
+struct PclImgList { const float* p[PCL_HIST_MAX_IMAGES]; };
+
 struct PclBinArgs {
     const float* cloud;
     int64_t n, stride;
@@ -320,9 +325,10 @@ extern "C" int pcl_debug_set_hist_trace(unsigned long long* buf)
 }
 #endif
 template <int PCL_RESOLVE_THREADS>
-__global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, const float* __restrict__ img, int nsh, int nsw,
+__global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, PclImgList imgs, int cpi, int nsh, int nsw,
                                                                           unsigned int* __restrict__ ghist)
 {
+    const float* __restrict__ img = imgs.p[(int)blockIdx.x / cpi];       // (blockIdx.x = candidate)
     // the tile with a halo of two pixels: every splat pixel of every listed entry has a cell (an entry is listed when its 3 x 3
     // splat touches the tile, so its centre is at most one pixel outside), and the nine writes need no membership test
     constexpr int TW = PCL_TS + 4;
@@ -457,9 +463,11 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
 // MODE 0: query image (zbuf unused, cand = 0)   MODE 1: candidate renders
 template <int MODE>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ cloud,
-                                                                   int64_t stride, const float* __restrict__ img, int H, int W, int nsh,
+                                                                   int64_t stride, PclImgList imgs, int cpi, int H, int W, int nsh,
                                                                    int nsw, unsigned int* __restrict__ ghist)
 {
+    // MODE 0: blockIdx.y = query image (its own histograms);  MODE 1: blockIdx.y = candidate, scored against image cand / cpi
+    const float* __restrict__ img = imgs.p[MODE == 0 ? (int)blockIdx.y : (int)blockIdx.y / cpi];
     __shared__ unsigned int hist[PCL_HBINS];
     const int blk = blockIdx.x / PCL_HSUB, sub = blockIdx.x - blk * PCL_HSUB, cand = blockIdx.y, nblk = gridDim.x / PCL_HSUB;
     const int bh = H / nsh, bw = W / nsw;
@@ -493,10 +501,11 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigne
 }
 
 // MODE 0: qhist[blk][512] = hist / hist.sum(), nimg[blk].   MODE 1: inter[cand][blk] = sum min(h / h.sum(), qhist), nproj.
+// (MODE 0: blockIdx.y = query image; MODE 1: blockIdx.y = candidate, intersected with the histograms of image cand / cpi)
 template <int MODE>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_final_kernel(const unsigned int* __restrict__ ghist, float* __restrict__ qhist,
                                                                    int* __restrict__ nimg, float* __restrict__ inter,
-                                                                   int* __restrict__ nproj)
+                                                                   int* __restrict__ nproj, int cpi)
 {
     __shared__ float red[PCL_BLOCK / PCL_WAVE];
     const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x;
@@ -508,11 +517,12 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_final_kernel(const unsigne
     float total = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
     if (MODE == 0) {
-        qhist[(int64_t)blk * PCL_HBINS + threadIdx.x] = (float)c0 / total;              // hist / hist.sum()
-        qhist[(int64_t)blk * PCL_HBINS + threadIdx.x + PCL_BLOCK] = (float)c1 / total;
-        if (threadIdx.x == 0) nimg[blk] = (int)total;
+        float* q = qhist + ((int64_t)cand * nblk + blk) * PCL_HBINS;                    // (cand = query image here)
+        q[threadIdx.x] = (float)c0 / total;                                             // hist / hist.sum()
+        q[threadIdx.x + PCL_BLOCK] = (float)c1 / total;
+        if (threadIdx.x == 0) nimg[(int64_t)cand * nblk + blk] = (int)total;
     } else {
-        const float* qh = qhist + (int64_t)blk * PCL_HBINS;
+        const float* qh = qhist + ((int64_t)(cand / cpi) * nblk + blk) * PCL_HBINS;
         float v = fminf((float)c0 / total, qh[threadIdx.x]) + fminf((float)c1 / total, qh[threadIdx.x + PCL_BLOCK]);
         if (!(total > 0.f)) v = 0.f;
         v = pcl_wave_sum(v);
@@ -565,12 +575,13 @@ static size_t hist_render_bytes(int64_t n, int H, int W)
     return binned > zb ? binned : zb;
 }
 
-static size_t hist_workspace_bytes(int64_t n, int ncand, int H, int W, int nsh, int nsw)
+static size_t hist_workspace_bytes(int64_t n, int ncand, int H, int W, int nsh, int nsw, int nimages = 1)
 {
-    if (ncand <= 0 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return 0;
+    if (ncand <= 0 || nimages <= 0 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return 0;
     const size_t nblk = (size_t)(nsh - 2) * nsw;
     return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * hist_render_bytes(n, H, W)) +
-           hist_align(nblk * PCL_HBINS * sizeof(float)) + hist_align((size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int));
+           hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float)) +
+           hist_align((size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int));
 }
 
 extern "C" size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw)
@@ -583,17 +594,31 @@ extern "C" size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh
     return hist_workspace_bytes(0, ncand, H, W, nsh, nsw);
 }
 
-extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* img_hwc, int H, int W,
-                                    const float* trans, const float* rot, int ncand, int nsh, int nsw, float* inter, int* nproj,
-                                    int* nimg, void* workspace, size_t workspace_bytes, void* stream)
+extern "C" size_t pcl_hist_trim_images_workspace_bytes(int64_t n, int nimages, int cand_per_image, int H, int W, int nsh, int nsw)
 {
-    if (!cloud || !img_hwc || !trans || !rot || !inter || !nproj || !nimg || !workspace) return PCL_EINVAL;
-    if (n <= 0 || n > 0x1fffffffll || ncand <= 0 || ncand > 65535 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
+    if (n <= 0 || nimages <= 0 || nimages > PCL_HIST_MAX_IMAGES || cand_per_image <= 0) return 0;
+    return hist_workspace_bytes(n, nimages * cand_per_image, H, W, nsh, nsw, nimages);
+}
+
+// candidates [i * cand_per_image, (i + 1) * cand_per_image) are scored against imgs_host[i]; nimg [nimages][nblk]
+extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const float* const* imgs_host, int nimages, int cand_per_image, int H,
+                                           int W, const float* trans, const float* rot, int nsh, int nsw, float* inter, int* nproj,
+                                           int* nimg, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !imgs_host || !trans || !rot || !inter || !nproj || !nimg || !workspace) return PCL_EINVAL;
+    if (nimages <= 0 || nimages > PCL_HIST_MAX_IMAGES || cand_per_image <= 0) return PCL_EINVAL;
+    const int ncand = nimages * cand_per_image, cpi = cand_per_image;
+    PclImgList imgs;
+    for (int i = 0; i < PCL_HIST_MAX_IMAGES; i++) {
+        imgs.p[i] = i < nimages ? imgs_host[i] : nullptr;
+        if (i < nimages && !imgs_host[i]) return PCL_EINVAL;
+    }
+    if (n <= 0 || n > 0x1fffffffll || ncand > 65535 || H <= 0 || W <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
     if (H / nsh <= 0 || W / nsw <= 0) return PCL_EINVAL;
-    if (workspace_bytes < pcl_hist_trim_workspace_bytes(ncand, H, W, nsh, nsw)) return PCL_EWORKSPACE;
-    // a workspace of pcl_hist_trim_workspace_bytes_n(n, ...) selects the tile-binned path, the smaller one of
-    // pcl_hist_trim_workspace_bytes(...) the z-buffer splat
-    const bool roomy = workspace_bytes >= hist_workspace_bytes(n, ncand, H, W, nsh, nsw);
+    if (workspace_bytes < hist_workspace_bytes(0, ncand, H, W, nsh, nsw, nimages)) return PCL_EWORKSPACE;
+    // a workspace sized with n (pcl_hist_trim_workspace_bytes_n / pcl_hist_trim_images_workspace_bytes) selects the tile-binned
+    // path, the smaller one of pcl_hist_trim_workspace_bytes(...) the z-buffer splat
+    const bool roomy = workspace_bytes >= hist_workspace_bytes(n, ncand, H, W, nsh, nsw, nimages);
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     PclPoseRec* recs = (PclPoseRec*)ws;
@@ -602,16 +627,16 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
     ws += hist_align((size_t)ncand * hist_render_bytes(roomy ? n : 0, H, W));
     float* qhist = (float*)ws;
     const int nblk = (nsh - 2) * nsw;
-    ws += hist_align((size_t)nblk * PCL_HBINS * sizeof(float));
-    unsigned int* ghist_q = (unsigned int*)ws;                       // [nblk][512], then [ncand][nblk][512]
-    unsigned int* ghist_c = ghist_q + (size_t)nblk * PCL_HBINS;
-    hipError_t me = hipMemsetAsync(ghist_q, 0, (size_t)(ncand + 1) * nblk * PCL_HBINS * sizeof(unsigned int), s);
+    ws += hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float));
+    unsigned int* ghist_q = (unsigned int*)ws;                       // [nimages][nblk][512], then [ncand][nblk][512]
+    unsigned int* ghist_c = ghist_q + (size_t)nimages * nblk * PCL_HBINS;
+    hipError_t me = hipMemsetAsync(ghist_q, 0, (size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int), s);
     if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     const int64_t stride = pcl_cloud_stride(n);
-    hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, 1), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
-                       cloud, stride, img_hwc, H, W, nsh, nsw, ghist_q);
-    hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, 1), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, nimages), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
+                       cloud, stride, imgs, cpi, H, W, nsh, nsw, ghist_q);
+    hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, nimages), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj, cpi);
     // Tile-binned path when the caller sized the workspace for it.  PCL_HIST_SPLAT=1 forces the z-buffer path (tests compare
     // the two bit for bit).
     const int force_splat = pcl_hist_env_int("PCL_HIST_SPLAT", 0);      // (read per call: a handful of calls per image)
@@ -649,8 +674,8 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
         }
         const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
         const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
-        if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, img_hwc, nsh, nsw, ghist_c);
-        else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, img_hwc, nsh, nsw, ghist_c);
+        if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, imgs, cpi, nsh, nsw, ghist_c);
+        else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, imgs, cpi, nsh, nsw, ghist_c);
     } else {
         hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
         // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
@@ -661,12 +686,20 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
         constexpr int TH = 64, TW = 64, PTS = 256;
         hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
                            dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
-        hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, img_hwc, H, W,
+        hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, imgs, cpi, H, W,
                            nsh, nsw, ghist_c);
     }
-    hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj);
+    hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj, cpi);
     PCL_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* img_hwc, int H, int W,
+                                    const float* trans, const float* rot, int ncand, int nsh, int nsw, float* inter, int* nproj,
+                                    int* nimg, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return pcl_hist_trim_scores_images(cloud, n, &img_hwc, 1, ncand, H, W, trans, rot, nsh, nsw, inter, nproj, nimg, workspace, workspace_bytes,
+                                       stream);
 }
 
 // Scores with the reference's slot semantics.  The reference keeps ONE vector `hist_intersect_split` of nsh * nsw slots for
@@ -681,10 +714,16 @@ extern "C" int pcl_hist_trim_scores(const float* cloud, int64_t n, const float* 
 // Candidates go through in chunks that fit the LDS table; no barrier inside the walk (the first version synchronised twice
 // per candidate: 78 us per call for 64 candidates).
 #define PCL_SCORE_LDS_FLOATS 6144
-__global__ void __launch_bounds__(256) pcl_hist_score_kernel(const float* __restrict__ inter, const int* __restrict__ nproj,
-                                                             const int* __restrict__ nimg, int ncand, int nsh, int nsw,
-                                                             float* __restrict__ score)
+__global__ void __launch_bounds__(256) pcl_hist_score_kernel(const float* __restrict__ inter_all, const int* __restrict__ nproj_all,
+                                                             const int* __restrict__ nimg_all, int ncand, int nsh, int nsw,
+                                                             float* __restrict__ score_all)
 {
+    // one block per query image: its ncand candidates form their own chain (the reference's slot vector lives in one call of
+    // trim_input_hist_secondary, i.e. one image)
+    const float* __restrict__ inter = inter_all + (int64_t)blockIdx.x * ncand * ((nsh - 2) * nsw);
+    const int* __restrict__ nproj = nproj_all + (int64_t)blockIdx.x * ncand * ((nsh - 2) * nsw);
+    const int* __restrict__ nimg = nimg_all + (int64_t)blockIdx.x * ((nsh - 2) * nsw);
+    float* __restrict__ score = score_all + (int64_t)blockIdx.x * ncand;
     __shared__ float eff[PCL_SCORE_LDS_FLOATS];           // [chunk][nblk]: slot contents after each candidate of the chunk
     __shared__ float carry_slot[1024];                    // carried slot values between chunks (nblk <= 1024)
     __shared__ int brk[PCL_SCORE_LDS_FLOATS];             // [chunk][rows]: first empty block of the row (nsw if none)
@@ -730,12 +769,18 @@ __global__ void __launch_bounds__(256) pcl_hist_score_kernel(const float* __rest
     }
 }
 
+extern "C" int pcl_hist_trim_reduce_images(const float* inter, const int32_t* nproj, const int32_t* nimg, int nimages, int cand_per_image, int nsh,
+                                           int nsw, float* score, void* stream)
+{
+    if (!inter || !nproj || !nimg || !score || nimages <= 0 || cand_per_image <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
+    if ((nsh - 2) * nsw > 1024) return PCL_EINVAL;        // > 1024 blocks: not a block grid this stage is meant for
+    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3(nimages), dim3(256), 0, (hipStream_t)stream, inter, nproj, nimg, cand_per_image, nsh, nsw, score);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pcl_hist_trim_reduce(const float* inter, const int32_t* nproj, const int32_t* nimg, int ncand, int nsh, int nsw, float* score,
                                     void* stream)
 {
-    if (!inter || !nproj || !nimg || !score || ncand <= 0 || nsh < 3 || nsw < 1) return PCL_EINVAL;
-    if ((nsh - 2) * nsw > 1024) return PCL_EINVAL;        // > 1024 blocks: not a block grid this stage is meant for
-    hipLaunchKernelGGL(pcl_hist_score_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, inter, nproj, nimg, ncand, nsh, nsw, score);
-    PCL_LAUNCH_CHECK();
-    return 0;
+    return pcl_hist_trim_reduce_images(inter, nproj, nimg, 1, ncand, nsh, nsw, score, stream);
 }

@@ -313,6 +313,45 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
     return scores
 
 
+HIST_MAX_IMAGES = 32       # pcl_hist_trim_scores_images: query images per call
+
+
+def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
+    """hist_trim_scores for several query images of one room in ONE set of launches: imgs = list of I (H, W, 3) float GPU images of
+    one size, trans / rot (I, K, 3): image i's K candidates.  -> (I, K) scores, row i what hist_trim_scores(imgs[i], ...) returns
+    (bit for bit: same keys, same integer counts, one carry-over chain per image).  Images go through in groups that keep the
+    point lists within ~8 GB."""
+    lib = _lib.load()
+    imgs = [_dev(im) for im in imgs]
+    trans, rot = _dev(trans), _dev(rot)
+    I, K = int(trans.shape[0]), int(trans.shape[1])
+    H, W = int(imgs[0].shape[0]), int(imgs[0].shape[1])
+    if len(imgs) != I or any(tuple(im.shape) != (H, W, 3) or not im.is_contiguous() for im in imgs):
+        raise ValueError("hist_trim_scores_images: one contiguous (H, W, 3) image per row of candidates, all of one size")
+    nblk = (num_split_h - 2) * num_split_w
+    dev = imgs[0].device
+    inter = torch.empty(I * K, nblk, dtype=F32, device=dev)
+    nproj = torch.empty(I * K, nblk, dtype=torch.int32, device=dev)
+    nimg = torch.empty(I, nblk, dtype=torch.int32, device=dev)
+    scores = torch.empty(I, K, dtype=F32, device=dev)
+    per_image = max(lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w), 1)
+    if lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w) == 0:
+        raise ValueError("hist_trim_scores_images: need num_split_h >= 3 and blocks of at least one pixel")
+    group = max(1, min(HIST_MAX_IMAGES, I, int(8e9 // per_image)))
+    t2, r2 = trans.reshape(I * K, 3).contiguous(), rot.reshape(I * K, 3).contiguous()
+    for i0 in range(0, I, group):
+        m = min(group, I - i0)
+        nws = lib.pcl_hist_trim_images_workspace_bytes(cloud.n, m, K, H, W, num_split_h, num_split_w)
+        ws = _bytes(nws)
+        arr = (ctypes.c_void_p * m)(*[im.data_ptr() for im in imgs[i0:i0 + m]])
+        _lib.check(lib.pcl_hist_trim_scores_images(_ptr(cloud.data), cloud.n, arr, m, K, H, W, _ptr(t2[i0 * K:]), _ptr(r2[i0 * K:]), num_split_h,
+                                                   num_split_w, _ptr(inter[i0 * K:]), _ptr(nproj[i0 * K:]), _ptr(nimg[i0:]), _ptr(ws), nws, _stream()),
+                   "pcl_hist_trim_scores_images")
+        _lib.check(lib.pcl_hist_trim_reduce_images(_ptr(inter[i0 * K:]), _ptr(nproj[i0 * K:]), _ptr(nimg[i0:]), m, K, num_split_h, num_split_w,
+                                                   _ptr(scores[i0:]), _stream()), "pcl_hist_trim_reduce_images")
+    return scores
+
+
 def depth_mask(cloud, trans, rot, resolution, tau=0.02):
     """(B, n) uint8 GPU tensor in PACKED point order: scatter-min visibility of every point for every pose."""
     lib = _lib.load()

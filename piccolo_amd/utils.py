@@ -328,7 +328,8 @@ def make_input(img, xyz, rgb, num_input, init_dict=None, criterion="histogram", 
 def make_input_images(imgs, xyz, rgb, num_input, init_dict=None, criterion="histogram", num_intermediate=None):
     """make_input for SEVERAL query images of one room (throughput extension; the reference's image loop, localize.py:143-223,
     calls make_input once per image although the candidate grid depends on the cloud only, utils.py:613-616): ONE trim launch
-    over image x translation x rotation, one selection launch for all images, the second stage per image, one final selection.
+    over image x translation x rotation, one selection launch for all images, the second stage for all images' survivors in one set
+    of launches, one final selection.
     Returns [(input_trans, input_rot)] per image — the tensors make_input returns for that image, bit for bit (the trim launch
     cuts the cloud into the single-image launch's chunks; tests/test_hip_harness.py)."""
     from .omniloc import _cached
@@ -354,8 +355,7 @@ def make_input_images(imgs, xyz, rgb, num_input, init_dict=None, criterion="hist
     groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot))
     tables = ops.trim_loss_tables(cloud, panos, trans, groups).reshape(I, K * Rn)
     t1, r1 = ops.select_poses(tables, n_mid, trans, rot, largest=False, rot_per_trans=Rn)               # (I, n_mid, 3)
-    scores = torch.stack([ops.hist_trim_scores(imgs[i], cloud, t1[i], r1[i], init_dict["num_split_h"], init_dict["num_split_w"])
-                          for i in range(I)])
+    scores = ops.hist_trim_scores_images(imgs, cloud, t1, r1, init_dict["num_split_h"], init_dict["num_split_w"])        # (I, n_mid)
     ft, fr = ops.select_poses(scores, min(num_input, n_mid), t1, r1, largest=True)                      # (I, num_input, 3)
     return [(ft[i], fr[i]) for i in range(I)]
 

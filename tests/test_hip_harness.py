@@ -387,7 +387,11 @@ def test_make_input_images_equals_per_image_make_input():
         for i in range(I):
             t1, c1 = ops.trim_loss_table(cloud, panos[i], trans, groups, return_count=True)
             assert torch.equal(tabs[i], t1) and torch.equal(cnts[i], c1), i
-    # the dataset loops' batcher goes through it: 3 images per launch
+        # the second stage for all images at once: row i = the single-image call, bit for bit (non-contiguous slices included)
+        t1, r1 = ops.select_poses(tabs.reshape(I, -1), 50, trans, rot, rot_per_trans=len(rot))
+        both = ops.hist_trim_scores_images(imgs, cloud, t1, r1, d["num_split_h"], d["num_split_w"])
+        for i in range(I):
+            assert torch.equal(both[i], ops.hist_trim_scores(imgs[i], cloud, t1[i], r1[i], d["num_split_h"], d["num_split_w"])), i
     with pytest.raises(ValueError):
         ops.trim_loss_tables(cloud, [panos[0], ops.Pano(imgs[1], fmt="f32")], trans, groups)
 
