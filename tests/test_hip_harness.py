@@ -313,6 +313,17 @@ def test_select_poses_is_the_reference_argsort_and_decode():
     for p in range(P):
         want = ref_order(sc[p], 6, True)
         assert np.array_equal(tt[p].cpu().numpy(), pt[p][want]) and np.array_equal(tr[p].cpu().numpy(), pr[p][want])
+    # a table far larger than the block (every thread strides through it), all values distinct or all equal
+    M = 300_007
+    v = rng.permutation(M).astype(np.float32)
+    pt = rng.normal(size=(M, 3)).astype(np.float32)
+    tt, tr, idx = ops.select_poses(torch.from_numpy(v).to(dev), 1000, torch.from_numpy(pt).to(dev), torch.from_numpy(pt).to(dev), return_idx=True)
+    assert np.array_equal(idx.cpu().numpy(), ref_order(v, 1000, False)) and np.array_equal(tt.cpu().numpy(), pt[ref_order(v, 1000, False)])
+    same = torch.full((5000,), 0.5, device=dev)
+    _, _, idx = ops.select_poses(same, 7, torch.zeros(5000, 3, device=dev), torch.zeros(5000, 3, device=dev), return_idx=True)
+    assert idx.cpu().tolist() == list(range(7))                   # ties: ascending index
+    _, _, idx = ops.select_poses(same, 7, torch.zeros(5000, 3, device=dev), torch.zeros(5000, 3, device=dev), largest=True, return_idx=True)
+    assert idx.cpu().tolist() == list(range(4999, 4992, -1))      # largest: descending index (the flipped tail of the stable argsort)
     with pytest.raises(Exception):
         ops.select_poses(torch.zeros(10, device=dev), 11, torch.zeros(10, 3, device=dev), torch.zeros(10, 3, device=dev))
 
@@ -392,6 +403,18 @@ def test_make_input_images_equals_per_image_make_input():
         both = ops.hist_trim_scores_images(imgs, cloud, t1, r1, d["num_split_h"], d["num_split_w"])
         for i in range(I):
             assert torch.equal(both[i], ops.hist_trim_scores(imgs[i], cloud, t1[i], r1[i], d["num_split_h"], d["num_split_w"])), i
+    # more images than one launch takes (32 for the trim launch; the second stage is forced to groups of two here): the chunked
+    # calls give the same rows
+    many = [panos[i % I] for i in range(ops.TRIM_MAX_IMAGES + 3)]
+    tabs_many = ops.trim_loss_tables(cloud, many, trans, groups)
+    for i in range(len(many)):
+        assert torch.equal(tabs_many[i], tabs[i % I]), i
+    old_max = ops.HIST_MAX_IMAGES
+    try:
+        ops.HIST_MAX_IMAGES = 2
+        assert torch.equal(ops.hist_trim_scores_images(imgs, cloud, t1, r1, d["num_split_h"], d["num_split_w"]), both)
+    finally:
+        ops.HIST_MAX_IMAGES = old_max
     with pytest.raises(ValueError):
         ops.trim_loss_tables(cloud, [panos[0], ops.Pano(imgs[1], fmt="f32")], trans, groups)
 
