@@ -343,7 +343,7 @@ class Measure:
         rows, grp, tr, ro, table = item
         gd = self.gd_by_size[len(grp)]
         gd.reset(tr, ro)
-        gd.set_pano_table(table)
+        gd.set_pano_table(table, images=len(grp))
         gd.run(NUM_ITER, timer=tm)
         res = gd.result().reshape(len(grp), self.B, -1)
         k = torch.argmin(res[:, :, 12], dim=1)             # per image: smallest loss of the last forward

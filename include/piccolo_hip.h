@@ -147,6 +147,10 @@ typedef struct pcl_gd_hyper {
     int32_t depth_every;   /* and only when the mask in use has served at least depth_every loss passes (0 or 1: no such condition).   */
                            /* depth_every = k with bounds 0 / 0: the mask is recomputed at every k-th iteration, i.e. it is at most    */
                            /* k - 1 Adam steps old (<= (k - 1) * lr per parameter).                                                    */
+    int32_t images;        /* number of query images whose candidates share this launch chain (pcl_gd_set_panos / _set_pano_groups;   */
+                           /* image i's candidates a contiguous range).  0 / 1: one image.  A hint for the block -> XCD mapping only    */
+                           /* (with several panoramas every XCD takes a range of pose groups, i.e. of images, over the whole cloud      */
+                           /* instead of a slice of the cloud for all of them): results do not depend on it.                            */
 } pcl_gd_hyper;
 
 size_t pcl_gd_state_bytes(int B);

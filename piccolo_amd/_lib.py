@@ -21,7 +21,7 @@ PANO_F32, PANO_U8, PANO_F16, PANO_U8P = 0, 1, 2, 3
 class GdHyper(_c.Structure):
     _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32),
                 ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float), ("depth_refresh_t", _c.c_float), ("depth_refresh_r", _c.c_float),
-                ("depth_every", _c.c_int32)]
+                ("depth_every", _c.c_int32), ("images", _c.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/piccolo_hip.h declares

@@ -350,6 +350,11 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     // (PclFuseArgs) — no inter-block synchronisation, the kernel boundary is the only one; the last iteration is finished by
     // the stand-alone epilogue.  Same arithmetic in the same order: results are bit-identical to the two-launch form
     // (PCL_GD_FUSE_BLOCKS: largest grid that takes this path, 0 = never).
+    // several panoramas in the launch AND a cloud small enough to live in every XCD's L2 next to a texture (6 MB: the reference's
+    // shipped 167k points): the XCDs split the pose groups — the images — instead of the chunks (pcl_launch_loss).  Large clouds keep
+    // the chunk mapping: measured at 1M points, 8 images per launch +0.3 % (3 523 -> 3 533), 5 images per launch (the driver's shape:
+    // 10 groups per XCD straddling the images, every XCD walking the whole 24 MB cloud) -1.5 % (3 533 -> 3 479).
+    const int xcd_bit = hyper_host->images > 1 && n * 24 <= ((int64_t)6 << 20) ? 2 : 0;
     const int fuse_blocks = gd_fuse_limit();
     const bool fused = !visible && pcl_plan_nblocks(n, B) <= fuse_blocks;
     const int G = pcl_plan_G(n, B);
@@ -392,9 +397,9 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             f.st_out = gd_poses(state, B, cout); f.recs_out = gd_recs(state, B, cout);
             f.box = box; f.factor = hyper_host->factor; f.patience = (int)hyper_host->patience; f.mode = (int)hyper_host->mode;
             f.loss_out = loss_history ? loss_history + (int64_t)(it - 1) * B : nullptr;
-            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, f.recs_in, B, true, nullptr, partials2[cout], s, flip_env ? (it & 1) : 0, &f);
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, f.recs_in, B, true, nullptr, partials2[cout], s, (flip_env ? (it & 1) : 0) | xcd_bit, &f);
         } else {
-            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials2[0], s, flip_env ? (it & 1) : 0,
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials2[0], s, (flip_env ? (it & 1) : 0) | xcd_bit,
                                  nullptr);
         }
         if (rc) return rc;

@@ -37,6 +37,7 @@ struct PclLossArgs {
     int ngroups;             // B / G
     int flip;                    // 1: every XCD walks its chunks from the last to the first (see pcl_launch_loss)
     int seg_len;                 // chunks per contiguous run of one XCD (see the mapping at the top of pcl_loss_kernel)
+    int xcd_groups;              // 1: the XCDs split the pose groups (ngroups % 8 == 0), every XCD walks all chunks
     int steps_base, steps_rem;   // the cloud's ceil(n / PCL_STEP) steps are dealt out evenly: chunk c has steps_base + (c < steps_rem)
 };
 
@@ -78,10 +79,22 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
     // Measured at cfg 2, one image per launch chain (bench.py single_image, same box): 1 / 2 / 4 / 8 / 32 runs per XCD
     // 2802 / 2832 / 2889 / 2933 / 2988 candidate-poses/s, and 3047 with every chunk its own run (frac 0.86 -> 0.93);
     // 8 images per launch +0.7 %, cfg 5 +2.4 %; the 1800-pose forward launch is unchanged.
-    const int lq = (int)(blockIdx.x >> 3) / a.ngroups, group = (int)(blockIdx.x >> 3) - lq * a.ngroups;
-    const int lc = a.flip ? (a.nchunks >> 3) - 1 - lq : lq;                                             // chunk within the XCD
-    const int run = lc / a.seg_len;
-    const int chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lc - run * a.seg_len);
+    int group, chunk;
+    if (a.xcd_groups) {
+        // XCD <-> pose GROUPS instead of XCD <-> chunks (round 4): XCD x evaluates the groups [x * ngroups / 8, (x + 1) * ngroups / 8)
+        // over ALL chunks.  For launches whose candidates read DIFFERENT panoramas — the images of one room in one chain, image i's
+        // candidates a contiguous range of groups — an XCD's L2 then holds ONE image's texture (plus the whole of a small cloud)
+        // instead of a slice of the cloud and every texture of the launch.
+        const int gpx = a.ngroups >> 3, j = (int)(blockIdx.x >> 3), cj = j / gpx;
+        group = (int)(blockIdx.x & 7) * gpx + (j - cj * gpx);
+        chunk = a.flip ? a.nchunks - 1 - cj : cj;
+    } else {
+        const int lq = (int)(blockIdx.x >> 3) / a.ngroups;
+        group = (int)(blockIdx.x >> 3) - lq * a.ngroups;
+        const int lc = a.flip ? (a.nchunks >> 3) - 1 - lq : lq;                                         // chunk within the XCD
+        const int run = lc / a.seg_len;
+        chunk = (run * 8 + (int)(blockIdx.x & 7)) * a.seg_len + (lc - run * a.seg_len);
+    }
     const int pose0 = group * G;
 
     // the poses this block evaluates, as SGPR pairs: straight from the pose records, or (FUSED) out of the optimiser update below
@@ -386,7 +399,14 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
-    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.flip = flip; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
+    a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.flip = flip & 1; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
+    // bit 1 of `flip`: the poses of this launch read several panoramas (pcl_gd_hyper.images > 1) — the XCDs split the pose groups
+    // instead of the chunks when they divide evenly.  Measured per iteration (tools/iter_latency.py, ITER_IMAGES=8): 167k points x 48
+    // candidates of 8 images 64.0 -> 49.8 us (poses all over the room) / 51.3 -> 41.7 us (near the ground truth), 1M points x 256
+    // candidates of 8 images 797 -> 761 us.  The partial sums per (group, chunk) are the same: results unchanged bit for bit.
+    // PCL_XCD_GROUPS=0 / 1 forces the mapping off / on (A/B).
+    static const int xg_env = pcl_env_int("PCL_XCD_GROUPS", -1);
+    a.xcd_groups = ((flip & 2) != 0 || xg_env == 1) && xg_env != 0 && p.ngroups % 8 == 0 ? 1 : 0;
     int nblk = p.nchunks * p.ngroups;
     bool vis = visible != nullptr;
     if (fuse) {

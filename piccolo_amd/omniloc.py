@@ -192,7 +192,7 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
             g._box_src, g._fresh = box, True
             return g
         # (the fuse limit is read by pcl_gd_run per call but frozen into a captured graph: part of the key)
-        gd = _cached("gd", (xyz,), make_private, sub=(B, p0.H, p0.W, p0.fmt, os.environ.get("PCL_GD_FUSE_BLOCKS")) + hyper)
+        gd = _cached("gd", (xyz,), make_private, sub=(B, len(panos), p0.H, p0.W, p0.fmt, os.environ.get("PCL_GD_FUSE_BLOCKS")) + hyper)
         fresh, gd._fresh = gd._fresh, False                  # (a new engine was initialised with these very poses)
         if gd._cloud_src() is not cloud:                     # weak: the engine must not keep packed clouds of past images alive
             gd.cloud.data.copy_(cloud.data)

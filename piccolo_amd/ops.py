@@ -458,7 +458,7 @@ class GradientDescent:
         self.B = int(trans.shape[0])
         self.box = _dev(box).reshape(6)
         self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL,
-                                  1 if depth_mask else 0, float(depth_tau), float(depth_refresh_t), float(depth_refresh_r), int(depth_every))
+                                  1 if depth_mask else 0, float(depth_tau), float(depth_refresh_t), float(depth_refresh_r), int(depth_every), 0)
         self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
         self.ws_bytes = lib.pcl_gd_workspace_bytes(cloud.n, self.B, pano.H, pano.W, ctypes.byref(self.hyper))
         self.ws = _bytes(self.ws_bytes)
@@ -511,11 +511,14 @@ class GradientDescent:
             if (p.H, p.W, p.fmt) != (self.pano.H, self.pano.W, self.pano.fmt):
                 raise ValueError("all panoramas of a launch must share size and texel format")
         self._panos = list(panos)                      # keep them alive
-        self.set_pano_table(torch.tensor([p.data.data_ptr() for p in panos], dtype=torch.int64, device=self.state.device))
+        self.set_pano_table(torch.tensor([p.data.data_ptr() for p in panos], dtype=torch.int64, device=self.state.device),
+                            images=len({id(p) for p in panos}))
 
-    def set_pano_table(self, table):
+    def set_pano_table(self, table, images=0):
         """Same with a ready-made device tensor of B packed-panorama addresses (int64); the caller keeps the Pano
-        objects alive.  No host work besides the launch."""
+        objects alive.  No host work besides the launch.  `images`: how many query images the table names (image i's candidates
+        a contiguous range) — a hint for the block -> XCD mapping of the launches, results do not depend on it."""
+        self.hyper.images = int(images)
         assert table.dtype == torch.int64 and table.numel() == self.B and table.is_cuda
         _lib.check(_lib.load().pcl_gd_set_panos(_ptr(self.state), _ptr(table), self.B, _stream()), "pcl_gd_set_panos")
         self._pano_table = table
@@ -531,6 +534,7 @@ class GradientDescent:
             if (p.H, p.W, p.fmt) != (self.pano.H, self.pano.W, self.pano.fmt):
                 raise ValueError("all panoramas of a launch must share size and texel format")
         self._panos = list(panos)                      # keep them alive
+        self.hyper.images = I                          # (mapping hint for pcl_gd_run: the XCDs split the images)
         arr = (ctypes.c_uint64 * I)(*[p.data.data_ptr() for p in panos])
         _lib.check(lib.pcl_gd_set_pano_groups(_ptr(self.state), arr, I, self.B // I, _stream()), "pcl_gd_set_pano_groups")
 

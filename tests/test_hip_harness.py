@@ -261,6 +261,38 @@ def test_make_input_composed_matches_the_reference(oracle, parity):
             check_selection(dist.argmin(1), d["hist_hist_intersect"], n_in, np.abs(scores - d["hist_hist_intersect"]) + 1e-6, largest=True)
 
 
+def test_xcd_per_image_mapping_gives_the_same_bits():
+    """pcl_gd_hyper.images > 1 (set by set_pano_groups / set_panos): the XCDs split the pose groups — i.e. the query images — of a
+    multi-image launch chain instead of the chunks of the cloud.  A mapping hint only: every (group, chunk) partial sum, hence every
+    result, loss history and optimiser state is the same bit pattern as with the hint off; fused and two-launch shapes."""
+    from piccolo_amd import ops, synth
+    H, W, I, per = 64, 128, 8, 2
+    for n in (20_000, 300_000):                               # 8 groups: one launch per iteration / two
+        xyz, rgb = synth.box_room(n, 33)
+        dev = torch.device("cuda")
+        X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
+        cloud, box = ops.Cloud(X, C), ops.quantile_box(X, 0.05)
+        panos, tr, ro = [], [], []
+        for i in range(I):
+            t_gt, ypr_gt = synth.gt_pose(70 + i)
+            img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
+            panos.append(ops.Pano(img))
+            a, b = synth.start_poses(t_gt, ypr_gt, per, seed=i)
+            tr.append(a); ro.append(b)
+        T_, R_ = torch.from_numpy(np.concatenate(tr)).to(dev), torch.from_numpy(np.concatenate(ro)).to(dev)
+        out = []
+        for hint in (True, False):
+            gd = ops.GradientDescent(cloud, panos[0], T_, R_, box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
+            gd.set_pano_groups(panos)
+            assert gd.hyper.images == I
+            if not hint:
+                gd.hyper.images = 0
+            hist = gd.run(12, history=True)
+            out.append((hist.clone(), gd.result().clone(), gd.state.clone()[: I * per * (160 + 64)]))
+        for a, b in zip(*out):
+            assert torch.equal(a, b), n
+
+
 def test_select_poses_is_the_reference_argsort_and_decode():
     """pcl_select_poses against numpy's stable argsort: utils.py:500-505 (ascending, `// len(rot)`, `% len(rot)`) and
     utils.py:583-586 (the flipped tail of the ascending argsort), with ties, NaNs (ranked last), -0.0 / +0.0, negative values,
