@@ -435,6 +435,11 @@ def test_make_input_images_equals_per_image_make_input():
         both = ops.hist_trim_scores_images(imgs, cloud, t1, r1, d["num_split_h"], d["num_split_w"])
         for i in range(I):
             assert torch.equal(both[i], ops.hist_trim_scores(imgs[i], cloud, t1[i], r1[i], d["num_split_h"], d["num_split_w"])), i
+    # eight images in one launch: the XCDs split the IMAGES instead of the chunks (pcl_trim.hip, xcd_images) — the same rows
+    eight = [panos[i % I] for i in range(8)]
+    tabs8 = ops.trim_loss_tables(cloud, eight, trans, groups)
+    for i in range(8):
+        assert torch.equal(tabs8[i], tabs[i % I]), i
     # more images than one launch takes (32 for the trim launch; the second stage is forced to groups of two here): the chunked
     # calls give the same rows
     many = [panos[i % I] for i in range(ops.TRIM_MAX_IMAGES + 3)]
