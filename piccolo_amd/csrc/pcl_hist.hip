@@ -325,10 +325,10 @@ extern "C" int pcl_debug_set_hist_trace(unsigned long long* buf)
 }
 #endif
 template <int PCL_RESOLVE_THREADS>
-__global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, PclImgList imgs, int cpi, int nsh, int nsw,
-                                                                          unsigned int* __restrict__ ghist)
+__global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_kernel(PclBinArgs a, const uint8_t* __restrict__ qmask, const uint16_t* __restrict__ codes, int cpi,
+                                                                          int nsh, int nsw, unsigned int* __restrict__ ghist)
 {
-    const float* __restrict__ img = imgs.p[(int)blockIdx.x / cpi];       // (blockIdx.x = candidate)
+    const uint8_t* __restrict__ qm = qmask + (int64_t)((int)blockIdx.x / cpi) * a.H * a.W;      // (blockIdx.x = candidate)
     // the tile with a halo of two pixels: every splat pixel of every listed entry has a cell (an entry is listed when its 3 x 3
     // splat touches the tile, so its centre is at most one pixel outside), and the nine writes need no membership test
     constexpr int TW = PCL_TS + 4;
@@ -419,13 +419,11 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
         const int h = r / bh, w = c / bw;
         if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // only the middle block rows (utils.py:556)
         const int64_t pix = (int64_t)r * a.W + c;
-        const float q0 = img[3 * pix], q1 = img[3 * pix + 1], q2 = img[3 * pix + 2];
-        if (q0 == 0.f && q1 == 0.f && q2 == 0.f) continue;               // query pixel black
+        if (!qm[pix]) continue;                                          // query pixel black (byte mask written with the query histograms)
         const int64_t j = (int64_t)(0x1fffffffu - (uint32_t)(k & 0x1fffffffull));
-        // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
-        const float p0 = -a.cloud[3 * a.stride + j] * 255.f, p1 = -a.cloud[4 * a.stride + j] * 255.f, p2 = -a.cloud[5 * a.stride + j] * 255.f;
-        if (p0 == 0.f && p1 == 0.f && p2 == 0.f) continue;
-        const int code = pcl_hist_code(p0, p1, p2), blk = (h - 1) * nsw + w;
+        const int code = (int)codes[j];                                  // the winner's 8 x 8 x 8 colour code (pcl_hist_codes_kernel)
+        if (code == 0xffff) continue;                                    // its colour is exactly black
+        const int blk = (h - 1) * nsw + w;
         const int sh = h - h_lo, sw = w - w_lo;
         if (sh < 2 && sw < 2) atomicAdd(&hist[sh * 2 + sw][code], 1u);
         else atomicAdd(&g[(int64_t)blk * PCL_HBINS + code], 1u);
@@ -455,6 +453,18 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
 }
 
 
+// 8 x 8 x 8 colour code of every packed point (0xffff: colour exactly black, never counted): what the resolve kernel needs of a
+// winner — one 2-byte gather instead of three 4-byte gathers from three planes.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_codes_kernel(const float* __restrict__ cloud, int64_t n, int64_t stride,
+                                                                   uint16_t* __restrict__ codes)
+{
+    const int64_t j = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (j >= n) return;
+    // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
+    const float p0 = -cloud[3 * stride + j] * 255.f, p1 = -cloud[4 * stride + j] * 255.f, p2 = -cloud[5 * stride + j] * 255.f;
+    codes[j] = (p0 == 0.f && p1 == 0.f && p2 == 0.f) ? (uint16_t)0xffffu : (uint16_t)pcl_hist_code(p0, p1, p2);
+}
+
 // Histograms in two steps so that a handful of image blocks still fills the chip: every (block, candidate) is cut into
 // PCL_HSUB pixel ranges, each range is histogrammed in LDS by its own workgroup and its non-empty bins are added to a
 // global counter array (integer atomics: deterministic); a finalise kernel then normalises / intersects.
@@ -464,10 +474,11 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
 template <int MODE>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigned long long* __restrict__ zbuf, const float* __restrict__ cloud,
                                                                    int64_t stride, PclImgList imgs, int cpi, int H, int W, int nsh,
-                                                                   int nsw, unsigned int* __restrict__ ghist)
+                                                                   int nsw, unsigned int* __restrict__ ghist, uint8_t* __restrict__ qmask)
 {
     // MODE 0: blockIdx.y = query image (its own histograms);  MODE 1: blockIdx.y = candidate, scored against image cand / cpi
     const float* __restrict__ img = imgs.p[MODE == 0 ? (int)blockIdx.y : (int)blockIdx.y / cpi];
+    uint8_t* __restrict__ qmask_out = (MODE == 0 && qmask) ? qmask + (int64_t)blockIdx.y * H * W : nullptr;
     __shared__ unsigned int hist[PCL_HBINS];
     const int blk = blockIdx.x / PCL_HSUB, sub = blockIdx.x - blk * PCL_HSUB, cand = blockIdx.y, nblk = gridDim.x / PCL_HSUB;
     const int bh = H / nsh, bw = W / nsw;
@@ -483,6 +494,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigne
         float q0 = img[3 * pix], q1 = img[3 * pix + 1], q2 = img[3 * pix + 2];
         bool qm = !(q0 == 0.f && q1 == 0.f && q2 == 0.f);            // query pixel not black
         if (MODE == 0) {
+            if (qmask_out) qmask_out[pix] = qm ? 1 : 0;              // what the resolve kernel asks of the query image: one byte, not 12
             if (qm) atomicAdd(&hist[pcl_hist_code(q0 * 255.f, q1 * 255.f, q2 * 255.f)], 1u);
         } else {
             unsigned long long k = zb[pix];
@@ -581,7 +593,8 @@ static size_t hist_workspace_bytes(int64_t n, int ncand, int H, int W, int nsh, 
     const size_t nblk = (size_t)(nsh - 2) * nsw;
     return hist_align((size_t)ncand * sizeof(PclPoseRec)) + hist_align((size_t)ncand * hist_render_bytes(n, H, W)) +
            hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float)) +
-           hist_align((size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int));
+           hist_align((size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int)) +
+           (n > 0 ? hist_align((size_t)nimages * H * W) + hist_align((size_t)n * sizeof(uint16_t)) : 0);     // query masks, colour codes
 }
 
 extern "C" size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw)
@@ -630,12 +643,15 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
     ws += hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float));
     unsigned int* ghist_q = (unsigned int*)ws;                       // [nimages][nblk][512], then [ncand][nblk][512]
     unsigned int* ghist_c = ghist_q + (size_t)nimages * nblk * PCL_HBINS;
+    ws += hist_align((size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int));
+    uint8_t* qmask = roomy ? (uint8_t*)ws : nullptr;                 // [nimages][H * W] (tile-binned path only)
+    uint16_t* codes = roomy ? (uint16_t*)(ws + hist_align((size_t)nimages * H * W)) : nullptr;
     hipError_t me = hipMemsetAsync(ghist_q, 0, (size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int), s);
     if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     const int64_t stride = pcl_cloud_stride(n);
     hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, nimages), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
-                       cloud, stride, imgs, cpi, H, W, nsh, nsw, ghist_q);
+                       cloud, stride, imgs, cpi, H, W, nsh, nsw, ghist_q, qmask);
     hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, nimages), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj, cpi);
     // Tile-binned path when the caller sized the workspace for it.  PCL_HIST_SPLAT=1 forces the z-buffer path (tests compare
     // the two bit for bit).
@@ -656,6 +672,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)
         me = hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
         if (me != hipSuccess) return (int)me;
+        hipLaunchKernelGGL(pcl_hist_codes_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0, s, cloud, n, stride, codes);
         dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
         const size_t win_bytes = 0;      // (the LDS-window form of the dedup lived here)
         // pre-dedup pays where pixels hold several points: measured at 1M points on 2048 x 1024 (0.5 points per pixel) resolve 613 ->
@@ -674,8 +691,8 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         }
         const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
         const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
-        if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, imgs, cpi, nsh, nsw, ghist_c);
-        else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, imgs, cpi, nsh, nsw, ghist_c);
+        if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, qmask, codes, cpi, nsh, nsw, ghist_c);
+        else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, qmask, codes, cpi, nsh, nsw, ghist_c);
     } else {
         hipLaunchKernelGGL(pcl_fill_u64b_kernel, dim3(2048), dim3(PCL_BLOCK), 0, s, zbuf, (int64_t)ncand * H * W, ~0ull);
         // 64 x 64-pixel LDS window (32 KB of 64-bit cells) per 256 consecutive (Morton-ordered) points: a compact surface
@@ -687,7 +704,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         hipLaunchKernelGGL((pcl_splat_poses_kernel<TH, TW, PTS>), dim3((unsigned)((n + PTS - 1) / PTS), (unsigned)ncand),
                            dim3(PCL_BLOCK), 0, s, cloud, n, stride, recs, H, W, zbuf);
         hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, imgs, cpi, H, W,
-                           nsh, nsw, ghist_c);
+                           nsh, nsw, ghist_c, (uint8_t*)nullptr);
     }
     hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj, cpi);
     PCL_LAUNCH_CHECK();
