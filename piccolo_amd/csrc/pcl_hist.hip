@@ -412,11 +412,15 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     const int bh = a.H / nsh, bw = a.W / nsw, nblk = (nsh - 2) * nsw;
     const int h_lo = (ty * PCL_TS) / bh, w_lo = (tx * PCL_TS) / bw;       // first histogram block row / column of this tile
     unsigned int* g = ghist + (int64_t)cand * nblk * PCL_HBINS;
+    const bool big_blocks = bh >= PCL_TS && bw >= PCL_TS;
     for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) {
         const unsigned long long k = tile[((i >> PCL_TS_SHIFT) + 2) * TW + (i & (PCL_TS - 1)) + 2];
         const int r = ty * PCL_TS + (i >> PCL_TS_SHIFT), c = tx * PCL_TS + (i & (PCL_TS - 1));
         if (k == ~0ull || r >= a.H || c >= a.W) continue;
-        const int h = r / bh, w = c / bw;
+        // (blocks at least a tile wide and high — every shipped config — span at most two block rows / columns per tile: a compare
+        //  instead of two integer divisions per pixel)
+        const int h = big_blocks ? h_lo + (r >= (h_lo + 1) * bh ? 1 : 0) : r / bh;
+        const int w = big_blocks ? w_lo + (c >= (w_lo + 1) * bw ? 1 : 0) : c / bw;
         if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // only the middle block rows (utils.py:556)
         const int64_t pix = (int64_t)r * a.W + c;
         if (!qm[pix]) continue;                                          // query pixel black (byte mask written with the query histograms)
