@@ -50,6 +50,45 @@ def box_room(n_points, seed=0):
     return xyz.astype(np.float32), rgb.astype(np.float32)
 
 
+# interior boxes of `furnished_room`: (centre, size) in metres — a pillar, a cabinet against a wall, a table-high block
+_FURNITURE = (((1.2, 0.6, 0.0), (0.5, 0.5, 3.0)), ((-2.6, -1.8, -0.5), (1.2, 0.6, 2.0)), ((0.3, -1.4, -1.0), (1.6, 0.9, 1.0)))
+
+
+def furnished_room(n_points, seed=0):
+    """The box room with three interior boxes (a floor-to-ceiling pillar, a cabinet, a low block): NOT convex, so from any pose part
+    of the walls / floor is hidden behind furniture — the case north_star's scatter-min depth mask exists for (a point that the
+    query panorama does not show still projects into it and samples the colour of whatever is in front).  Points by area over the
+    room's faces and the boxes' outer faces, same colour field as box_room."""
+    rng = np.random.default_rng(seed)
+    surfaces = []                                             # (axis, coordinate, (lo_a, hi_a), (lo_b, hi_b))
+    for axis in range(3):
+        a, b = [k for k in range(3) if k != axis]
+        for sign in (-1.0, 1.0):
+            surfaces.append((axis, sign * ROOM[axis] / 2, (-ROOM[a] / 2, ROOM[a] / 2), (-ROOM[b] / 2, ROOM[b] / 2)))
+    for c, sz in _FURNITURE:
+        for axis in range(3):
+            a, b = [k for k in range(3) if k != axis]
+            for sign in (-1.0, 1.0):
+                surfaces.append((axis, c[axis] + sign * sz[axis] / 2, (c[a] - sz[a] / 2, c[a] + sz[a] / 2), (c[b] - sz[b] / 2, c[b] + sz[b] / 2)))
+    areas = np.array([(s[2][1] - s[2][0]) * (s[3][1] - s[3][0]) for s in surfaces])
+    which = rng.choice(len(surfaces), size=n_points, p=areas / areas.sum())
+    u, v = rng.random(n_points), rng.random(n_points)
+    xyz = np.empty((n_points, 3), dtype=np.float64)
+    for i, (axis, coord, ra, rb) in enumerate(surfaces):
+        m = which == i
+        a, b = [k for k in range(3) if k != axis]
+        xyz[m, axis] = coord
+        xyz[m, a] = ra[0] + u[m] * (ra[1] - ra[0])
+        xyz[m, b] = rb[0] + v[m] * (rb[1] - rb[0])
+    rgb = 0.5 + 0.45 * np.sin(xyz @ _K.T + _PHI)
+    return xyz.astype(np.float32), rgb.astype(np.float32)
+
+
+def inside_furniture(t, margin=0.3):
+    """True if position t is within `margin` of one of furnished_room's boxes (no camera there)."""
+    return any(all(abs(float(t[k]) - c[k]) <= sz[k] / 2 + margin for k in range(3)) for c, sz in _FURNITURE)
+
+
 def gt_pose(seed):
     """Ground-truth (t (3,), ypr (3,)) for query image `seed`: t in the central half of the room."""
     rng = np.random.default_rng(10_000 + seed)

@@ -740,6 +740,33 @@ def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
     assert not torch.equal(r_on[0], r_off[0])            # the mask changed the objective
 
 
+def test_depth_mask_on_a_room_with_furniture(ops):
+    """What the mask is for (tools/furnished_room.py at bench size): in synth.furnished_room part of the walls is hidden behind
+    boxes from any pose; those points project into the query panorama and sample the furniture's colour.  At the ground-truth
+    pose the mask hides them (a few % of the cloud) and the loss of what remains is far lower; in the convex box room it hides
+    next to nothing."""
+    from piccolo_amd import synth
+    n, H, W = 200_000, 512, 1024
+    image_id = next(i for i in range(40) if not synth.inside_furniture(synth.gt_pose(i)[0]))
+    t_gt, ypr_gt = synth.gt_pose(image_id)
+    stats = {}
+    for name, room in (("furnished", synth.furnished_room), ("box", synth.box_room)):
+        xyz, rgb = room(n, 3)
+        X, C = T(xyz), T(rgb)
+        cloud = ops.Cloud(X, C)
+        img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
+        pano = ops.Pano(img)
+        tg, rg = T(t_gt.reshape(1, 3)), T(ypr_gt.reshape(1, 3))
+        vis = ops.depth_mask(cloud, tg, rg, (H, W), tau=0.02)
+        plain = float(ops.sampling_loss(cloud, pano, tg, rg, with_grad=False)[0, 0])
+        masked = float(ops.sampling_loss(cloud, pano, tg, rg, with_grad=False, visible=vis)[0, 0])
+        stats[name] = (plain, masked, 1.0 - float(vis.float().mean()))
+    plain, masked, hidden = stats["furnished"]
+    assert 0.03 < hidden < 0.25, stats
+    assert masked < 0.75 * plain, stats
+    assert stats["box"][2] < 0.5 * hidden and stats["box"][1] > 0.8 * stats["box"][0], stats
+
+
 def test_depth_mask_refresh_bound(ops):
     """cfg depth_refresh_t / depth_refresh_r (build-defined, include/piccolo_hip.h): a candidate's depth mask is recomputed only
     when its forward pose has left the bound around the pose the mask in use was computed for.  Bounds of 0 = the mask of the
