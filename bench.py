@@ -552,23 +552,32 @@ def pipeline_images_block(sc, ipl=8, n_groups=3, num_input=6, num_intermediate=5
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1]))}
 
 
-def depth_mask_block(sc, B, n_images=2):
-    """north_star's scatter-min depth mask in the loop: the refinement of one query image's B candidates through the
-    GradientDescent engine with cfg depth_mask (per candidate: z pass with atomicMin into its own H x W buffer, byte mask of the
-    points within (1 + tau) of their pixel's minimum, masked loss launch) — a fresh mask at every iteration (the literal form) and
-    at every 4th (cfg depth_every; the product's setting for this cloud: Adam's steps stay near lr, so pose-distance bounds skip
-    almost nothing).  Whole 100-iteration refinements timed from the host; medians over `n_images` images."""
-    out = {"workload": "%d points, %dx%d, %d candidates, 1 image per launch chain, 100 iterations" % (sc.N, sc.W, sc.H, B)}
-    for name, kw in (("every_iteration", dict(depth_every=1)), ("every_4th_iteration", dict(depth_every=4))):
-        times, errs, masks = [], [], []
+def depth_mask_block(sc, B, n_images=2, panorama_grid=True):
+    """north_star's scatter-min depth mask in the loop: the refinement of one query image's B candidates through the GradientDescent
+    engine with cfg depth_mask — at EVERY iteration fill + z pass (LDS-tiled atomicMin into each candidate's own z-buffer) for the
+    poses that iteration evaluates, then the loss launch that looks each point's cell up (no mark pass, no byte mask; DESIGN.md
+    section 4.5).  `default_grid`: the product's default (pcl_depth_default: the z-buffer from every 2nd point of a 1M-point cloud
+    on the grid that count calls for, >= 12 occluder samples per cell; every point tested); `every_point`: depth_stride = 1, every
+    point builds the z-buffer (on its finer grid); `panorama_grid`: the z-buffer at the panorama's resolution with tau 0.02 — round 4's definition, kept as a priced comparison
+    (tools/depth_recall.py: it finds a third of the occluded points); `plain`: the same refinements without the mask, the
+    denominator of `x_plain`.  Whole 100-iteration refinements timed from the host; medians over `n_images` images."""
+    dh, dw, dtau, dst = ops.default_depth(sc.N, sc.H, sc.W)
+    h1, w1, t1, _ = ops.default_depth(sc.N, sc.H, sc.W, stride=1)
+    out = {"workload": "%d points, %dx%d, %d candidates, 1 image per launch chain, 100 iterations" % (sc.N, sc.W, sc.H, B),
+           "default_depth_res": [dh, dw], "default_depth_tau": dtau, "default_depth_stride": dst,
+           "every_point_depth_res": [h1, w1], "every_point_depth_tau": t1}
+    variants = [("plain", dict()), ("default_grid", dict(depth_mask=True)), ("every_point", dict(depth_mask=True, depth_stride=1))]
+    if panorama_grid:
+        variants.append(("panorama_grid", dict(depth_mask=True, depth_res=(sc.H, sc.W), depth_tau=0.02)))
+    for name, kw in variants:
+        times, errs = [], []
         gd = None
         for j in range(n_images + 1):
             image_id = 4_000_000 + j
             tr, ro, _ = sc.starts(image_id, B)
             pano = sc.image(image_id)["pano"]
             if gd is None:
-                gd = ops.GradientDescent(sc.cloud, pano, tr, ro, sc.box, lr=LR, patience=PATIENCE, factor=FACTOR, batch_mode=True,
-                                         depth_mask=True, **kw)
+                gd = ops.GradientDescent(sc.cloud, pano, tr, ro, sc.box, lr=LR, patience=PATIENCE, factor=FACTOR, batch_mode=True, **kw)
             else:
                 gd.reset(tr, ro)
                 gd.set_pano_table(torch.full((B,), pano.data.data_ptr(), dtype=torch.int64, device=sc.dev))
@@ -585,12 +594,13 @@ def depth_mask_block(sc, B, n_images=2):
             R = ops.rot_from_ypr(torch.from_numpy(res[k:k + 1, 3:6]))[0].cpu().numpy()
             errs.append(synth.pose_errors(res[k, :3], R, gt[0], synth.rot_from_ypr_np(gt[1])))
             times.append(dt)
-            masks.append(float(gd.depth_refresh_counts().float().mean()))
         errs = np.array(errs)
         out[name] = {"value": B / float(np.median(times)), "unit": "candidate-poses/s", "us_per_iteration": float(np.median(times)) / NUM_ITER * 1e6,
-                     "masks_computed_per_candidate": float(np.mean(masks)),
                      "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1]))}
         del gd
+    for name in ("default_grid", "every_point", "panorama_grid"):
+        if name in out:
+            out[name]["x_plain"] = out[name]["us_per_iteration"] / out["plain"]["us_per_iteration"]
     return out
 
 
@@ -806,7 +816,7 @@ def main():
                 also["pipeline_shipped_8_images"] = pipeline_images_block(scenes[(166_667, 1024, 2048)], ipl=8)
             if (1_000_000, 1024, 2048) in scenes and world == 1:
                 also["depth_mask_cfg2"] = depth_mask_block(scenes[(1_000_000, 1024, 2048)], 32)
-                also["depth_mask_cfg3"] = depth_mask_block(scenes[(1_000_000, 1024, 2048)], 256, n_images=1)
+                also["depth_mask_cfg3"] = depth_mask_block(scenes[(1_000_000, 1024, 2048)], 256, n_images=1, panorama_grid=False)
             if args.workload != "cfg5" and world == 1:
                 also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)
         except Exception as exc:                        # the headline must survive a failing side measurement

@@ -11,17 +11,17 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RESULT_STRIDE = 8
-GD_RESULT_STRIDE = 14
+GD_RESULT_STRIDE = 16
 GD_SEQUENTIAL, GD_BATCH = 0, 1
 PANO_F32, PANO_U8, PANO_F16, PANO_U8P = 0, 1, 2, 3
 
 
 class GdHyper(_c.Structure):
     _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32),
-                ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float), ("depth_refresh_t", _c.c_float), ("depth_refresh_r", _c.c_float),
-                ("depth_every", _c.c_int32), ("images", _c.c_int32)]
+                ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float), ("depth_h", _c.c_int32), ("depth_w", _c.c_int32),
+                ("depth_stride", _c.c_int32), ("images", _c.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/piccolo_hip.h declares
@@ -42,6 +42,9 @@ SIGNATURES = {
     "pcl_pano_pack_f16": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
     "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_loss_depth_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
+    "pcl_sampling_loss_depth": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _int, _int, _c.c_float, _int, _vp, _vp, _sz, _vp]),
+    "pcl_depth_default": (_int, [_i64, _int, _int, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_c.c_float), _c.POINTER(_int)]),
     "pcl_gd_state_bytes": (_sz, [_int]),
     "pcl_gd_workspace_bytes": (_sz, [_i64, _int, _int, _int, _c.POINTER(GdHyper)]),
     "pcl_hist_trim_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
@@ -69,7 +72,7 @@ SIGNATURES = {
     "pcl_trim_loss_images_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
     "pcl_trim_loss_images": (_int, [_vp, _i64, _c.POINTER(_vp), _int, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "pcl_depth_workspace_bytes": (_sz, [_int, _int, _int]),
-    "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _vp, _vp, _sz, _vp]),
+    "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _int, _vp, _vp, _sz, _vp]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),
     "pcl_gd_run": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _int, _vp, _c.POINTER(GdHyper), _int, _vp, _vp, _sz, _vp, _vp]),
     "pcl_timer_create": (_vp, [_int]),
@@ -79,7 +82,7 @@ SIGNATURES = {
     "pcl_timer_read": (_int, [_vp, _c.POINTER(_dbl), _c.POINTER(_int)]),
     "pcl_timer_calibrate": (_int, [_vp, _int, _c.POINTER(_dbl), _vp]),
     "pcl_gd_result": (_int, [_vp, _int, _vp, _vp]),
-    "pcl_gd_depth_refresh_counts": (_int, [_vp, _int, _vp, _vp]),
+    "pcl_gd_step_from_grads": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcl_gd_plan": (_int, [_i64, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_plan_hyper": (_int, [_i64, _int, _c.POINTER(GdHyper), _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_int)]),
     "pcl_gd_set_panos": (_int, [_vp, _vp, _int, _vp]),

@@ -73,6 +73,31 @@ __host__ __device__ inline PclDims pcl_make_dims(int H, int W, int pano_format =
     return d;
 }
 
+// The scatter-min depth mask's z-buffer as the projecting kernels see it (build-defined, csrc/pcl_depth.hip): an Hd x Wd grid of
+// make_pano's pixels (utils.py:158-165) per pose, cell = bit pattern of the smallest squared depth that fell into it.
+//   col = trunc((gx + 1) / 2 (Wd - 1)),   row = trunc((gy + 1) / 2 (Hd - 1))              (pcl_depth_cells2, pcl_sample_device.h)
+// straight from the UNCLIPPED angles of pcl_angles2 — the z pass and the lookup in the loss kernel run the same instructions on
+// the same inputs, so a point looks its own cell up.
+struct PclDepthGrid {
+    int Hd, Wd, last;           // last = Hd * Wd - 1
+    float wm1, hm1;             // Wd - 1, Hd - 1
+    float tol2;                 // (1 + tau)^2.  The z pass stores min(d2 * tol2) = tol2 * min d2 (rounding is monotone): visible iff d2 <= cell
+};
+__host__ __device__ inline PclDepthGrid pcl_make_depth_grid(int Hd, int Wd, float tau)
+{
+    PclDepthGrid g;
+    g.Hd = Hd; g.Wd = Wd; g.last = Hd * Wd - 1;
+    g.wm1 = (float)(Wd - 1); g.hm1 = (float)(Hd - 1);
+    g.tol2 = (1.0f + tau) * (1.0f + tau);
+    return g;
+}
+// what a loss launch needs to look the mask up (pcl_launch_loss)
+struct PclDepthLook {
+    const uint32_t* zbuf;       // [B][Hd * Wd]
+    PclDepthGrid grid;
+    uint32_t* zclear;           // nullable: another set of z-buffers (zclear_vec4 16-byte words) that the loss launch resets to +inf
+    int64_t zclear_vec4;
+};
 // R = RZ(yaw) RY(pitch) RX(roll) (reference utils.py:425-453). sin/cos are evaluated in double and rounded once,
 // which lands within an ulp of the fp32 values ATen computes on the host.
 __device__ inline void pcl_rot_from_ypr(float yaw, float pitch, float roll, float R[9])

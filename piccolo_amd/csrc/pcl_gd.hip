@@ -12,14 +12,16 @@
 #define PCL_GD_MAX_IMAGES 64     // panorama addresses per pcl_gd_set_pano_groups launch (they travel as kernel arguments)
 
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse);
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse,
+                    const PclDepthLook* depth);
 size_t pcl_partials_bytes(int64_t n, int B);
 int pcl_plan_nchunks(int64_t n, int B);
 int pcl_plan_nblocks(int64_t n, int B);
 int pcl_plan_G(int64_t n, int B);
-size_t pcl_depth_zbuf_bytes(int B, int H, int W);
-int pcl_launch_depth_mask(const float* cloud, int64_t n, const PclPoseRec* poses, int B, int H, int W, float tau,
-                          uint32_t* zbuf, uint8_t* visible, const uint32_t* refresh, int refresh_stride, hipStream_t s);
+size_t pcl_depth_zbuf_bytes(int B, int Hd, int Wd);
+int pcl_launch_zbuffers(const float* cloud, int64_t n, const PclPoseRec* poses, int B, const PclDepthGrid& g, int zstride, uint32_t* zbuf, bool fill,
+                        hipStream_t s);
+extern "C" int pcl_depth_default(int64_t n, int H, int W, int stride_in, int* depth_h_host, int* depth_w_host, float* tau_host, int* stride_host);
 
 // ---------------------------------------------------------------- stateless loss: pose setup + finish
 
@@ -64,6 +66,17 @@ extern "C" size_t pcl_loss_workspace_bytes(int64_t n, int B)
     return (size_t)B * sizeof(PclPoseRec) + pcl_partials_bytes(n, B);
 }
 
+static int pcl_finish_launch(const float* partials, int64_t n, int B, const PclPoseRec* recs, const float* rot, int with_grad, float* result,
+                             hipStream_t s)
+{
+    const int G = pcl_plan_G(n, B), nch = pcl_plan_nchunks(n, B);
+    if (G == 4) hipLaunchKernelGGL(pcl_finish_kernel<4>, dim3(B / 4), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
+    else if (G == 2) hipLaunchKernelGGL(pcl_finish_kernel<2>, dim3(B / 2), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
+    else hipLaunchKernelGGL(pcl_finish_kernel<1>, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
+    PCL_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans,
                                  const float* rot, int B, int with_grad, const uint8_t* visible, float* result,
                                  void* workspace, size_t workspace_bytes, void* stream)
@@ -76,14 +89,61 @@ extern "C" int pcl_sampling_loss(const float* cloud, int64_t n, const void* pano
     float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
     hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
     PCL_LAUNCH_CHECK();
-    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s, 0, nullptr);
+    int rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, visible, partials, s, 0, nullptr, nullptr);
     if (rc) return rc;
-    const int G = pcl_plan_G(n, B), nch = pcl_plan_nchunks(n, B);
-    if (G == 4) hipLaunchKernelGGL(pcl_finish_kernel<4>, dim3(B / 4), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
-    else if (G == 2) hipLaunchKernelGGL(pcl_finish_kernel<2>, dim3(B / 2), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
-    else hipLaunchKernelGGL(pcl_finish_kernel<1>, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nch, B, recs, rot, with_grad, result);
-    PCL_LAUNCH_CHECK();
+    return pcl_finish_launch(partials, n, B, recs, rot, with_grad, result, s);
+}
+
+// the grid and occluder stride a depth-masked call uses: the caller's, or pcl_depth_default's for 0 x 0 / stride 0 (a given grid
+// without a stride: every point builds the z-buffer)
+static int gd_depth_grid(int64_t n, int H, int W, int depth_h, int depth_w, float tau, int stride_in, PclDepthGrid* g, int* stride)
+{
+    if (depth_h < 0 || depth_w < 0 || (depth_h == 0) != (depth_w == 0) || !(tau >= 0.f) || stride_in < 0 || stride_in > 64) return PCL_EINVAL;
+    int st = stride_in;
+    if (depth_h == 0) {
+        int rc = pcl_depth_default(n, H, W, stride_in, &depth_h, &depth_w, nullptr, &st);
+        if (rc) return rc;
+    } else if (st == 0) st = 1;
+    if (stride) *stride = st;
+    if (depth_h < 2 || depth_w < 2 || (int64_t)depth_h * depth_w > ((int64_t)1 << 28)) return PCL_EINVAL;
+    *g = pcl_make_depth_grid(depth_h, depth_w, tau);
     return 0;
+}
+
+static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t pcl_loss_depth_workspace_bytes(int64_t n, int B, int H, int W, int depth_h, int depth_w)
+{
+    PclDepthGrid g;
+    if (n <= 0 || B <= 0 || gd_depth_grid(n, H, W, depth_h, depth_w, 0.f, 0, &g, nullptr)) return 0;
+    return gd_align(pcl_loss_workspace_bytes(n, B)) + pcl_depth_zbuf_bytes(B, g.Hd, g.Wd);
+}
+
+// pcl_sampling_loss with the scatter-min depth mask of the SAME poses multiplied into the mask: pose records, fill + z pass
+// (pcl_depth.hip), loss launch that looks every point's cell up, finish.  Four launches, no byte mask.
+extern "C" int pcl_sampling_loss_depth(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans,
+                                       const float* rot, int B, int with_grad, int depth_h, int depth_w, float tau, int depth_stride, float* result,
+                                       void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !pano || !trans || !rot || !result || !workspace || n <= 0 || B <= 0 || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (n > PCL_MAX_POINTS) return PCL_EINVAL;
+    PclDepthLook look;
+    int zstride = 1;
+    int rc = gd_depth_grid(n, H, W, depth_h, depth_w, tau, depth_stride, &look.grid, &zstride);
+    if (rc) return rc;
+    if (workspace_bytes < pcl_loss_depth_workspace_bytes(n, B, H, W, depth_h, depth_w)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    PclPoseRec* recs = (PclPoseRec*)workspace;
+    float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
+    uint32_t* zbuf = (uint32_t*)((char*)workspace + gd_align(pcl_loss_workspace_bytes(n, B)));
+    look.zbuf = zbuf; look.zclear = nullptr; look.zclear_vec4 = 0;
+    hipLaunchKernelGGL(pcl_pose_setup_kernel, dim3((B + 255) / 256), dim3(256), 0, s, trans, rot, B, recs);
+    PCL_LAUNCH_CHECK();
+    rc = pcl_launch_zbuffers(cloud, n, recs, B, look.grid, zstride, zbuf, true, s);
+    if (rc) return rc;
+    rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, recs, B, with_grad != 0, nullptr, partials, s, 0, nullptr, &look);
+    if (rc) return rc;
+    return pcl_finish_launch(partials, n, B, recs, rot, with_grad, result, s);
 }
 
 // ---------------------------------------------------------------- GD: state init, epilogue, run, result
@@ -96,57 +156,6 @@ static inline PclGdPose* gd_poses(void* state, int B = 0, int copy = 0) { return
 static inline PclPoseRec* gd_recs(void* state, int B, int copy = 0)
 {
     return (PclPoseRec*)((char*)state + (size_t)copy * gd_copy_bytes(B) + (size_t)B * sizeof(PclGdPose));
-}
-
-// Depth-mask refresh record of a candidate (behind the two state copies): the forward pose its current mask was computed for, the
-// flag the depth passes of this iteration read, and how many times the mask has been computed.
-struct PclDepthSnap {
-    float pose[6];
-    uint32_t refresh, count, age, pad[3];      // age: loss passes the mask in use has served
-};
-static_assert(sizeof(PclDepthSnap) == 48, "depth refresh record");
-static inline PclDepthSnap* gd_snaps(void* state, int B) { return (PclDepthSnap*)((char*)state + 2 * gd_copy_bytes(B)); }
-
-// refresh[b] = the mask in use has served at least `every` loss passes AND the forward pose of candidate b moved by more than
-// thr_t in a translation component or thr_r in an angle since that mask was computed (always true for a fresh state: the
-// snapshot starts as NaN).  Thresholds of 0: whenever it moved at all — an unmoved pose has an unchanged mask, so with every = 1
-// that is exactly "the current pose's mask at every iteration".
-__global__ void pcl_depth_refresh_kernel(const PclGdPose* __restrict__ st, PclDepthSnap* snaps, int B, float thr_t, float thr_r, int every)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    PclDepthSnap sn = snaps[b];
-    bool moved = false;
-    for (int k = 0; k < 6; k++) {
-        const float d = fabsf(st[b].fwd[k] - sn.pose[k]);
-        moved = moved || !(d <= (k < 3 ? thr_t : thr_r));            // (NaN snapshot: not <=, so moved)
-    }
-    const bool fresh = sn.pose[0] != sn.pose[0];
-    const bool go = moved && (fresh || sn.age >= (uint32_t)every);
-    sn.refresh = go ? 1u : 0u;
-    if (go) {
-        for (int k = 0; k < 6; k++) sn.pose[k] = st[b].fwd[k];
-        sn.count += 1u;
-        sn.age = 0u;
-    }
-    sn.age += 1u;
-    snaps[b] = sn;
-}
-
-__global__ void pcl_depth_snap_init_kernel(PclDepthSnap* snaps, int B)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    PclDepthSnap sn;
-    for (int k = 0; k < 6; k++) sn.pose[k] = __builtin_nanf("");
-    sn.refresh = 1u; sn.count = 0u; sn.age = 0u; sn.pad[0] = sn.pad[1] = sn.pad[2] = 0u;
-    snaps[b] = sn;
-}
-
-__global__ void pcl_depth_snap_count_kernel(const PclDepthSnap* __restrict__ snaps, int B, int* __restrict__ out)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) out[b] = (int)snaps[b].count;
 }
 
 __global__ void pcl_gd_init_kernel(PclGdPose* st, PclPoseRec* recs, PclPoseRec* recs_shadow, const float* __restrict__ trans,
@@ -180,6 +189,17 @@ __global__ void __launch_bounds__(PCL_GD_THREADS) pcl_gd_epilogue_kernel(const f
                                   loss_out, rows_sh, sums_sh, nullptr);
 }
 
+// the epilogue's update path driven by a GIVEN loss and gradient per candidate (one block per candidate, G = 1)
+__global__ void __launch_bounds__(PCL_GD_THREADS) pcl_gd_forced_kernel(const float* __restrict__ zero_partials, PclGdPose* st, PclPoseRec* recs,
+                                                                       const float* __restrict__ box, double factor, int patience, int mode,
+                                                                       const float* __restrict__ forced_loss, const float* __restrict__ forced_grad)
+{
+    __shared__ double rows_sh[(PCL_GD_THREADS / 16) * 2][4];
+    __shared__ double sums_sh[1][PCL_NACC];
+    pcl_gd_finish_group<1, false, true>(zero_partials, 1, blockIdx.x, threadIdx.x, st, recs, st, recs, true, box, factor, patience, mode, nullptr,
+                                        rows_sh, sums_sh, nullptr, forced_loss, forced_grad);
+}
+
 __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, float* __restrict__ result)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,17 +208,23 @@ __global__ void pcl_gd_result_kernel(const PclGdPose* __restrict__ st, int B, fl
     for (int k = 0; k < 6; k++) { r[k] = st[b].fwd[k]; r[6 + k] = st[b].leaf[k]; }
     r[12] = st[b].last_loss;
     r[13] = (float)st[b].lr;
+    r[14] = (float)st[b].num_bad;
+    r[15] = (float)st[b].best;
 }
 
-extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? 2 * gd_copy_bytes(B) + (size_t)B * sizeof(PclDepthSnap) : 0; }
-
-static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
+extern "C" size_t pcl_gd_state_bytes(int B) { return B > 0 ? 2 * gd_copy_bytes(B) : 0; }
 
 extern "C" size_t pcl_gd_workspace_bytes(int64_t n, int B, int H, int W, const pcl_gd_hyper* hyper_host)
 {
     if (n <= 0 || B <= 0 || !hyper_host) return 0;
     size_t bytes = 2 * gd_align(pcl_partials_bytes(n, B));         // (two: fused iterations read one while they write the other)
-    if (hyper_host->depth_mask) bytes += gd_align(pcl_depth_zbuf_bytes(B, H, W)) + gd_align((size_t)B * (size_t)n);
+    if (hyper_host->depth_mask) {
+        PclDepthGrid g;
+        if (gd_depth_grid(n, H, W, hyper_host->depth_h, hyper_host->depth_w, 0.f, hyper_host->depth_stride, &g, nullptr)) return 0;
+        // two sets: iteration k reads set k & 1 and resets the other one for iteration k + 1's z pass (no fill launch between
+        // iterations).  Scratch: every pcl_gd_run call fills set 0 itself before its first iteration, nothing persists in them.
+        bytes += 2 * gd_align(pcl_depth_zbuf_bytes(B, g.Hd, g.Wd));
+    }
     return bytes;
 }
 
@@ -207,8 +233,6 @@ extern "C" int pcl_gd_init(void* state, const float* trans, const float* rot, in
     if (!state || !trans || !rot || !hyper_host || B <= 0) return PCL_EINVAL;
     hipLaunchKernelGGL(pcl_gd_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_poses(state),
                        gd_recs(state, B), gd_recs(state, B, 1), trans, rot, B, hyper_host->lr);
-    if (hyper_host->depth_mask)
-        hipLaunchKernelGGL(pcl_depth_snap_init_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, gd_snaps(state, B), B);
     PCL_LAUNCH_CHECK();
     return 0;
 }
@@ -328,17 +352,25 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         return PCL_EINVAL;
     if (n > PCL_MAX_POINTS) return PCL_EINVAL;
     if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
-    if (workspace_bytes < pcl_gd_workspace_bytes(n, B, H, W, hyper_host)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* partials2[2] = {(float*)workspace, (float*)((char*)workspace + gd_align(pcl_partials_bytes(n, B)))};
-    uint32_t* zbuf = nullptr;
-    uint8_t* visible = nullptr;
+    PclDepthLook look;
+    look.zbuf = nullptr;
+    int zstride = 1;
     if (hyper_host->depth_mask) {
-        if (!(hyper_host->depth_tau >= 0.f) || B > 65535) return PCL_EINVAL;
-        if (!(hyper_host->depth_refresh_t >= 0.f) || !(hyper_host->depth_refresh_r >= 0.f) || hyper_host->depth_every < 0) return PCL_EINVAL;
-        zbuf = (uint32_t*)((char*)workspace + 2 * gd_align(pcl_partials_bytes(n, B)));
-        visible = (uint8_t*)zbuf + gd_align(pcl_depth_zbuf_bytes(B, H, W));
+        int rcg = gd_depth_grid(n, H, W, hyper_host->depth_h, hyper_host->depth_w, hyper_host->depth_tau, hyper_host->depth_stride, &look.grid, &zstride);
+        if (rcg) return rcg;
     }
+    const size_t need = pcl_gd_workspace_bytes(n, B, H, W, hyper_host);
+    if (need == 0 || workspace_bytes < need) return PCL_EWORKSPACE;
+    uint32_t* zbuf2[2] = {nullptr, nullptr};
+    if (hyper_host->depth_mask) {
+        zbuf2[0] = (uint32_t*)((char*)workspace + 2 * gd_align(pcl_partials_bytes(n, B)));
+        zbuf2[1] = (uint32_t*)((char*)zbuf2[0] + gd_align(pcl_depth_zbuf_bytes(B, look.grid.Hd, look.grid.Wd)));
+        look.zclear_vec4 = (int64_t)(pcl_depth_zbuf_bytes(B, look.grid.Hd, look.grid.Wd) / 16);
+    }
+    const bool depth_on = zbuf2[0] != nullptr;
+    static const int pingpong_env = getenv("PCL_ZPINGPONG") ? atoi(getenv("PCL_ZPINGPONG")) : 1;      // 0: a fill launch per iteration (A/B)
     const int nchunks = pcl_plan_nchunks(n, B);
     // odd iterations walk every XCD's chunks backwards: the first blocks of a launch then read the chunks the previous launch
     // finished with, still in that XCD's L2 (PCL_FLIP=0 turns it off; +0.3 % at cfg 2 in two A/B alternations on one box —
@@ -356,7 +388,7 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
     // 10 groups per XCD straddling the images, every XCD walking the whole 24 MB cloud) -1.5 % (3 533 -> 3 479).
     const int xcd_bit = hyper_host->images > 1 && n * 24 <= ((int64_t)6 << 20) ? 2 : 0;
     const int fuse_blocks = gd_fuse_limit();
-    const bool fused = !visible && pcl_plan_nblocks(n, B) <= fuse_blocks;
+    const bool fused = !depth_on && pcl_plan_nblocks(n, B) <= fuse_blocks;
     const int G = pcl_plan_G(n, B);
     auto epilogue = [&](int it, int copy_in, float* partials) {
         const PclGdPose* si = gd_poses(state, B, copy_in);
@@ -371,15 +403,16 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         else hipLaunchKernelGGL(pcl_gd_epilogue_kernel<1>, dim3(B), dim3(PCL_GD_THREADS), 0, s, partials, nchunks, si, ri, so, ro, box, fac, pat, mode, lo);
     };
     for (int it = 0; it < num_iter; it++) {
-        if (visible) {
-            // which candidates need a new mask: those whose forward pose left the refresh bound around the pose their mask
-            // was computed for; the depth passes of the others return at once (their z-buffer and byte mask stay)
-            PclDepthSnap* snaps = gd_snaps(state, B);
-            hipLaunchKernelGGL(pcl_depth_refresh_kernel, dim3((B + 255) / 256), dim3(256), 0, s, gd_poses(state, B, 0), snaps, B,
-                               hyper_host->depth_refresh_t, hyper_host->depth_refresh_r, hyper_host->depth_every > 1 ? hyper_host->depth_every : 1);
-            int rcd = pcl_launch_depth_mask(cloud, n, gd_recs(state, B), B, H, W, hyper_host->depth_tau, zbuf, visible, &snaps->refresh,
-                                            (int)(sizeof(PclDepthSnap) / sizeof(uint32_t)), s);
+        const PclDepthLook* depth = nullptr;
+        if (depth_on) {
+            // the scatter-min z-buffers of the poses this iteration evaluates: z pass into set it & 1 (filled by this call before its
+            // first iteration, reset by the previous iteration's loss launch afterwards); the loss launch looks them up
+            const int set = pingpong_env ? (it & 1) : 0;
+            int rcd = pcl_launch_zbuffers(cloud, n, gd_recs(state, B), B, look.grid, zstride, zbuf2[set], it == 0 || !pingpong_env, s);
             if (rcd) return rcd;
+            look.zbuf = zbuf2[set];
+            look.zclear = pingpong_env ? zbuf2[set ^ 1] : nullptr;
+            depth = &look;
         }
         // time every `stride`-th launch only: an event pair costs a few microseconds of GPU timeline, which would
         // distort short kernels if it bracketed all of them
@@ -397,10 +430,11 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
             f.st_out = gd_poses(state, B, cout); f.recs_out = gd_recs(state, B, cout);
             f.box = box; f.factor = hyper_host->factor; f.patience = (int)hyper_host->patience; f.mode = (int)hyper_host->mode;
             f.loss_out = loss_history ? loss_history + (int64_t)(it - 1) * B : nullptr;
-            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, f.recs_in, B, true, nullptr, partials2[cout], s, (flip_env ? (it & 1) : 0) | xcd_bit, &f);
-        } else {
-            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, visible, partials2[0], s, (flip_env ? (it & 1) : 0) | xcd_bit,
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, f.recs_in, B, true, nullptr, partials2[cout], s, (flip_env ? (it & 1) : 0) | xcd_bit, &f,
                                  nullptr);
+        } else {
+            rc = pcl_launch_loss(cloud, n, pano, pano_format, H, W, gd_recs(state, B), B, true, nullptr, partials2[0], s, (flip_env ? (it & 1) : 0) | xcd_bit,
+                                 nullptr, depth);
         }
         if (rc) return rc;
         if (timed) {
@@ -419,6 +453,20 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         epilogue(num_iter - 1, num_iter > 1 ? last : 0, partials2[num_iter > 1 ? last : 0]);
         PCL_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int pcl_gd_step_from_grads(void* state, int B, const float* loss, const float* grad, const float* box, const pcl_gd_hyper* hyper_host,
+                                      float* scratch, void* stream)
+{
+    if (!state || !loss || !grad || !box || !hyper_host || !scratch || B <= 0) return PCL_EINVAL;
+    if (hyper_host->mode != PCL_GD_SEQUENTIAL && hyper_host->mode != PCL_GD_BATCH) return PCL_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * PCL_NACC * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pcl_gd_forced_kernel, dim3(B), dim3(PCL_GD_THREADS), 0, s, scratch, gd_poses(state, B, 0), gd_recs(state, B, 0), box,
+                       hyper_host->factor, (int)hyper_host->patience, (int)hyper_host->mode, loss, grad);
+    PCL_LAUNCH_CHECK();
     return 0;
 }
 
@@ -475,25 +523,42 @@ extern "C" int pcl_gd_set_pano_groups(void* state, const uint64_t* panos_host, i
 // forward had the smallest loss (torch.argmin: the first of equal minima, and a NaN loss counts as the minimum), its post-step
 // translation, R = RZ RY RX of its post-step angles, that loss and the angles: 16 floats per image.  Also hands the leaf
 // parameters of all candidates back (the reference optimises views of the caller's tensors in place, omniloc.py:216-219).
-__global__ void pcl_gd_winner_kernel(const PclGdPose* __restrict__ st, int nimages, int per_image, float* __restrict__ out,
-                                     float* __restrict__ leaf_trans, float* __restrict__ leaf_rot)
+// One wave per image: lane-strided scan of the candidates' last losses, a wave argmin with torch.argmin's rules (a NaN beats any
+// number, among equals — or among NaNs — the smaller index wins), lane 0 writes the winner's 16 floats, all lanes the leaf rows.
+__global__ void __launch_bounds__(PCL_WAVE) pcl_gd_winner_kernel(const PclGdPose* __restrict__ st, int nimages, int per_image, float* __restrict__ out,
+                                                                 float* __restrict__ leaf_trans, float* __restrict__ leaf_rot)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nimages) return;
+    const int i = blockIdx.x, lane = threadIdx.x;
     const PclGdPose* s = st + (int64_t)i * per_image;
-    int k = 0;
-    float best = s[0].last_loss;
-    for (int b = 1; b < per_image && best == best; b++) {
+    float best = 0.f;
+    int k = 0x7fffffff;                                        // (no candidate yet)
+    auto better = [](float la, int ia, float lb, int ib) {     // is (la, ia) ahead of (lb, ib)?
+        if (ib == 0x7fffffff) return ia != 0x7fffffff;
+        if (ia == 0x7fffffff) return false;
+        const bool na = la != la, nb = lb != lb;
+        if (na != nb) return na;
+        if (na || la == lb) return ia < ib;
+        return la < lb;
+    };
+    for (int b = lane; b < per_image; b += PCL_WAVE) {
         const float l = s[b].last_loss;
-        if (l != l || l < best) { best = l; k = b; }
+        if (better(l, b, best, k)) { best = l; k = b; }
     }
-    float* o = out + (int64_t)i * 16;
-    float R[9];
-    pcl_rot_from_ypr(s[k].fwd[3], s[k].fwd[4], s[k].fwd[5], R);
-    for (int q = 0; q < 3; q++) { o[q] = s[k].fwd[q]; o[13 + q] = s[k].fwd[3 + q]; }
-    for (int q = 0; q < 9; q++) o[3 + q] = R[q];
-    o[12] = s[k].last_loss;
-    for (int b = 0; b < per_image; b++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float lo = __shfl_xor(best, o, 64);
+        const int ko = __shfl_xor(k, o, 64);
+        if (better(lo, ko, best, k)) { best = lo; k = ko; }
+    }
+    if (lane == 0) {
+        float* o = out + (int64_t)i * 16;
+        float R[9];
+        pcl_rot_from_ypr(s[k].fwd[3], s[k].fwd[4], s[k].fwd[5], R);
+        for (int q = 0; q < 3; q++) { o[q] = s[k].fwd[q]; o[13 + q] = s[k].fwd[3 + q]; }
+        for (int q = 0; q < 9; q++) o[3 + q] = R[q];
+        o[12] = s[k].last_loss;
+    }
+    for (int b = lane; b < per_image; b += PCL_WAVE) {
         const int64_t row = ((int64_t)i * per_image + b) * 3;
         for (int q = 0; q < 3; q++) {
             if (leaf_trans) leaf_trans[row + q] = s[b].leaf[q];
@@ -505,17 +570,8 @@ __global__ void pcl_gd_winner_kernel(const PclGdPose* __restrict__ st, int nimag
 extern "C" int pcl_gd_winner(const void* state, int nimages, int per_image, float* winners, float* leaf_trans, float* leaf_rot, void* stream)
 {
     if (!state || !winners || nimages <= 0 || per_image <= 0) return PCL_EINVAL;
-    hipLaunchKernelGGL(pcl_gd_winner_kernel, dim3((nimages + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const PclGdPose*)state, nimages,
+    hipLaunchKernelGGL(pcl_gd_winner_kernel, dim3(nimages), dim3(PCL_WAVE), 0, (hipStream_t)stream, (const PclGdPose*)state, nimages,
                        per_image, winners, leaf_trans, leaf_rot);
-    PCL_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pcl_gd_depth_refresh_counts(const void* state, int B, int* counts, void* stream)
-{
-    if (!state || !counts || B <= 0) return PCL_EINVAL;
-    hipLaunchKernelGGL(pcl_depth_snap_count_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const PclDepthSnap*)gd_snaps((void*)state, B), B, counts);
     PCL_LAUNCH_CHECK();
     return 0;
 }

@@ -123,11 +123,15 @@ struct PclFuseArgs {
 // reduction (stand-alone epilogue kernel).  `store`: write state, pose records and losses (the stand-alone kernel: always;
 // fused: the block of chunk 0).  `pose_sh` (nullable): LDS [G][12], receives R[9], t[3] of the poses the next forward uses.
 // in == out is allowed when a single block handles the group (stand-alone kernel).
-template <int G, bool ALL>
+// FORCED (pcl_gd_step_from_grads, the teacher-forcing hook of the parity tests): loss and gradient of every pose are READ from
+// forced_loss [B] / forced_grad [B][6] (t0, t1, t2, yaw, pitch, roll) instead of coming out of the sums; everything behind them —
+// Adam, scheduler, clamp, next pose record — is this very code.
+template <int G, bool ALL, bool FORCED = false>
 __device__ __forceinline__ void pcl_gd_finish_group(const float* __restrict__ partials, int nchunks, int grp, int tid,
                                                     const PclGdPose* st_in, const PclPoseRec* recs_in, PclGdPose* st_out, PclPoseRec* recs_out,
                                                     bool store, const float* __restrict__ box, double factor, int patience, int mode,
-                                                    float* loss_out, double (*rows_sh)[4], double (*sums_sh)[PCL_NACC], float (*pose_sh)[12])
+                                                    float* loss_out, double (*rows_sh)[4], double (*sums_sh)[PCL_NACC], float (*pose_sh)[12],
+                                                    const float* __restrict__ forced_loss = nullptr, const float* __restrict__ forced_grad = nullptr)
 {
     // torch evaluates the optimiser with separate, individually rounded tensor operations: no fused multiply-adds here
 #pragma clang fp contract(off)
@@ -164,7 +168,7 @@ __device__ __forceinline__ void pcl_gd_finish_group(const float* __restrict__ pa
 
         // loss and this lane's gradient component (pcl_chain_rule, one component per lane)
         const double M = s[1];
-        const float loss = (float)s[0] / (float)M;
+        float loss = (float)s[0] / (float)M;
         const double inv = 1.0 / M;
         const double sy = sc0, cy = sc1, sp = sc2, cp = sc3;
         float gk;
@@ -172,6 +176,7 @@ __device__ __forceinline__ void pcl_gd_finish_group(const float* __restrict__ pa
         else if (k == 3) gk = (float)(s[7] * inv);
         else if (k == 4) gk = (float)((-sy * s[5] + cy * s[6]) * inv);
         else gk = (float)((cy * cp * s[5] + sy * cp * s[6] - sp * s[7]) * inv);
+        if constexpr (FORCED) { loss = forced_loss[b]; gk = forced_grad[6 * b + k]; }
 
         // torch.optim.Adam, single-tensor form (betas 0.9/0.999, eps 1e-8; call sites omniloc.py:33,235-236):
         // fp32 tensor math, python-double scalars

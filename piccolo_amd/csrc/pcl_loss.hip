@@ -31,7 +31,12 @@ struct PclLossArgs {
     PclDims dims;
     const PclPoseRec* poses; // [B]
     int B;
-    const uint8_t* visible;  // nullable [B][n]
+    const uint8_t* visible;  // nullable [B][n]                                             (VIS == 1)
+    const uint32_t* zbuf;    // nullable [B][Hd * Wd]: the poses' z-buffers, pcl_depth.hip    (VIS == 2)
+    PclDepthGrid dgrid;
+    pcl_i4* zclear;          // nullable: the z-buffers the NEXT iteration's z pass fills — this launch resets them to +inf, a slice per block
+    int zclear_per_block;    //   (16-byte words per block; zclear_total in all), so that no fill launch stands between two iterations
+    int64_t zclear_total;
     float* partials;         // [ngroups][nchunks][G][8] (pcl_partials_row)
     int nchunks;             // multiple of 8
     int ngroups;             // B / G
@@ -62,11 +67,14 @@ extern "C" int pcl_debug_stamp(unsigned long long* slot, void* stream)
 }
 #endif
 
-// G poses per block, GRAD: with gradient, VIS: byte visibility mask, FMT: texel format.
+// G poses per block, GRAD: with gradient, FMT: texel format.
+// VIS: 0 = the reference's loss; 1 = a caller-supplied byte mask per point-pose multiplies into the mask; 2 = the scatter-min depth
+// mask looked up where it is needed: the pose's z-buffer (built by pcl_zpass_kernel for THIS pose just before the launch) is read at
+// the point's own cell while its texels are in flight, visible iff d^2 <= zmin^2 (1 + tau)^2 — no byte mask, no second projection.
 // (Forcing more resident blocks per CU through __launch_bounds__ was tried: the register allocator spills, 2-4x slower.)
 // FUSED: the block first finishes the PREVIOUS GD iteration for its own poses (PclFuseArgs, pcl_gd_device.h) and evaluates the
 // poses that come out of it; the block of chunk 0 also stores the optimiser state.  No block waits for another one.
-template <int G, bool GRAD, bool VIS, int FMT, bool FUSED>
+template <int G, bool GRAD, int VIS, int FMT, bool FUSED>
 __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFuseArgs& f)
 {
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch) and each XCD has its own 4 MiB L2.  Within an
@@ -104,6 +112,8 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
     // the cloud through a buffer resource too: 32-bit lane offsets + scalar plane offsets, no 64-bit address math
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
     const int plane = (int)a.stride * 4;
+    __amdgpu_buffer_rsrc_t zb = __amdgpu_buffer_rsrc_t();
+    if constexpr (VIS == 2) zb = __builtin_amdgcn_make_buffer_rsrc((void*)a.zbuf, 0, (int)((unsigned)a.B * (unsigned)(a.dgrid.last + 1) * 4u), 0x00020000);
 
     f2 acc[G][PCL_NACC];
     int count[G];
@@ -165,7 +175,7 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
             const PclPoseRec* __restrict__ pr = a.poses + (pose0 + g);
             bool ok0 = valid0, ok1 = valid1;
             unsigned long long m0 = vmask0, m1 = vmask1;
-            if (VIS) {
+            if constexpr (VIS == 1) {
                 const uint8_t* vis = a.visible + (int64_t)(pose0 + g) * a.n;
                 ok0 = ok0 && vis[min(i0, last)] != 0;
                 ok1 = ok1 && vis[min(i1, last)] != 0;
@@ -186,14 +196,23 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
+            const int zoff = VIS == 2 ? (pose0 + g) * (a.dgrid.last + 1) * 4 : 0;        // this pose's z-buffer (scalar offset)
 #ifndef PCL_NO_ROTATE_PAIR
             if constexpr (G == 2) {
                 pj.px = rot_p[g][0]; pj.py = rot_p[g][1]; pj.pz = rot_p[g][2];
-                pcl_project2_rotated<FMT>(tg, a.dims, pj);
+                pcl_project2_rotated<FMT, VIS == 2>(tg, a.dims, pj, zb, zoff, &a.dgrid);
             } else
 #endif
-            if constexpr (FUSED) pcl_project2<FMT>(x, y, z, P6[g], tg, a.dims, pj);
-            else pcl_project2<FMT>(x, y, z, pcl_pose6(pr), tg, a.dims, pj);
+            if constexpr (FUSED) pcl_project2<FMT, VIS == 2>(x, y, z, P6[g], tg, a.dims, pj, zb, zoff, &a.dgrid);
+            else pcl_project2<FMT, VIS == 2>(x, y, z, pcl_pose6(pr), tg, a.dims, pj, zb, zoff, &a.dgrid);
+            if constexpr (VIS == 2) {
+                // visible iff d^2 <= (zmin (1 + tau))^2 = the cell (the z pass stores the scaled minimum); an empty cell holds +inf
+                // (lane masks combined on the scalar unit — no short-circuit: a conditional look-up would split the loop body)
+                f2 d2 = pcl_fma2(pj.pz, pj.pz, pj.rho2);
+                const bool v0 = d2.x <= __uint_as_float(pj.zq0), v1 = d2.y <= __uint_as_float(pj.zq1);
+                ok0 = ok0 & v0; ok1 = ok1 & v1;
+                m0 = __builtin_amdgcn_ballot_w64(ok0); m1 = __builtin_amdgcn_ballot_w64(ok1);
+            }
             pcl_sample2<GRAD, FMT>(pj, ncr, ncg, ncb, ok0, ok1, m0, m1, tg, a.dims, acc[g], count[g]);
         }
     };
@@ -250,6 +269,16 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
         if (GRAD || k < 2) s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         a.partials[pcl_partials_row(a.nchunks, G, group, chunk, g) + k] = s;          // (one contiguous 32 G-byte row per block)
     }
+    // the other set of z-buffers, for the next iteration's z pass: this block's slice back to +inf.  At the END of the block: in front of
+    // the loop the slice's address arithmetic stayed live through it and the allocator gave up the four-wave budget (164 VGPRs).
+    if constexpr (VIS == 2) {
+        if (a.zclear) {
+            const pcl_i4 inf4 = {0x7f800000, 0x7f800000, 0x7f800000, 0x7f800000};
+            const int64_t z0 = (int64_t)blockIdx.x * a.zclear_per_block;
+            for (int i = threadIdx.x; i < a.zclear_per_block; i += PCL_BLOCK)
+                if (z0 + i < a.zclear_total) a.zclear[z0 + i] = inf4;
+        }
+    }
 #ifdef PCL_BLOCK_TRACE
     if (pcl_trace_buf && threadIdx.x == 0) {
         unsigned hw, xcc;
@@ -261,7 +290,7 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
 #endif
 }
 
-template <int G, bool GRAD, bool VIS, int FMT>
+template <int G, bool GRAD, int VIS, int FMT>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
 {
     pcl_loss_body<G, GRAD, VIS, FMT, false>(a, PclFuseArgs{});
@@ -270,7 +299,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_kernel(PclLossArgs a)
 template <int G, int FMT>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_fused_kernel(PclLossArgs a, PclFuseArgs f)
 {
-    pcl_loss_body<G, true, false, FMT, true>(a, f);
+    pcl_loss_body<G, true, 0, FMT, true>(a, f);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -359,19 +388,21 @@ void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int
 }
 
 template <int G, int FMT>
-static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, bool vis, hipStream_t s)
+static void pcl_launch_g(const PclLossArgs& a, int nblk, bool grad, int vis, hipStream_t s)
 {
     if (grad) {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, true, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, false, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        if (vis == 2) hipLaunchKernelGGL((pcl_loss_kernel<G, true, 2, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, true, 1, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, true, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
     } else {
-        if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, true, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, false, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        if (vis == 2) hipLaunchKernelGGL((pcl_loss_kernel<G, false, 2, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else if (vis) hipLaunchKernelGGL((pcl_loss_kernel<G, false, 1, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pcl_loss_kernel<G, false, 0, FMT>), dim3(nblk), dim3(PCL_BLOCK), 0, s, a);
     }
 }
 
 template <int FMT>
-static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, bool vis, hipStream_t s)
+static void pcl_launch_f(const PclLossArgs& a, int G, int nblk, bool grad, int vis, hipStream_t s)
 {
     if (G == 4) pcl_launch_g<4, FMT>(a, nblk, grad, vis, s);
     else if (G == 2) pcl_launch_g<2, FMT>(a, nblk, grad, vis, s);
@@ -388,8 +419,10 @@ static void pcl_launch_fused(const PclLossArgs& a, const PclFuseArgs& f, int G, 
 }
 
 // `fuse` (nullable): finish the previous GD iteration in the prologue of every block (gradient pass without visibility only)
+// `depth` (nullable): the poses' z-buffers and their grid — the scatter-min depth mask looked up inside the kernel (VIS == 2)
 int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const PclPoseRec* poses,
-                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse)
+                    int B, bool grad, const uint8_t* visible, float* partials, hipStream_t s, int flip, const PclFuseArgs* fuse,
+                    const PclDepthLook* depth)
 {
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return PCL_EINVAL;
     // 32-bit buffer addressing: 6 planes x 4 B x n must stay below 4 GiB, the padded panorama below 2 GiB
@@ -399,6 +432,19 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     a.cloud = cloud; a.n = n; a.stride = pcl_cloud_stride(n);
     a.pano = pano; a.dims = pcl_make_dims(H, W, pano_format);
     a.poses = poses; a.B = B; a.visible = visible; a.partials = partials;
+    a.zbuf = nullptr; a.dgrid = PclDepthGrid{};
+    a.zclear = nullptr; a.zclear_per_block = 0; a.zclear_total = 0;
+    if (depth) {
+        if (visible || !depth->zbuf || depth->grid.Hd <= 0 || depth->grid.Wd <= 0) return PCL_EINVAL;
+        if ((int64_t)B * depth->grid.Hd * depth->grid.Wd * 4 >= ((int64_t)1 << 32)) return PCL_EINVAL;     // one 32-bit buffer descriptor
+        a.zbuf = depth->zbuf; a.dgrid = depth->grid;
+        if (depth->zclear) {
+            const int64_t nblk64 = (int64_t)p.nchunks * p.ngroups;
+            a.zclear = (pcl_i4*)depth->zclear;
+            a.zclear_total = depth->zclear_vec4;
+            a.zclear_per_block = (int)((depth->zclear_vec4 + nblk64 - 1) / nblk64);
+        }
+    }
     a.nchunks = p.nchunks; a.ngroups = p.ngroups; a.seg_len = p.seg_len; a.flip = flip & 1; a.steps_base = p.steps_base; a.steps_rem = p.steps_rem;
     // bit 1 of `flip`: the poses of this launch read several panoramas (pcl_gd_hyper.images > 1) — the XCDs split the pose groups
     // instead of the chunks when they divide evenly.  Measured per iteration (tools/iter_latency.py, ITER_IMAGES=8): 167k points x 48
@@ -408,7 +454,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     static const int xg_env = pcl_env_int("PCL_XCD_GROUPS", -1);
     a.xcd_groups = ((flip & 2) != 0 || xg_env == 1) && xg_env != 0 && p.ngroups % 8 == 0 ? 1 : 0;
     int nblk = p.nchunks * p.ngroups;
-    bool vis = visible != nullptr;
+    const int vis = depth ? 2 : visible != nullptr ? 1 : 0;
     if (fuse) {
         if (!grad || vis) return PCL_EINVAL;
         if (pano_format == PCL_PANO_U8) pcl_launch_fused<PCL_PANO_U8>(a, *fuse, p.G, nblk, s);

@@ -164,7 +164,22 @@ struct PclProj {
     f2 fx, fy;            // bilinear fractions
     bool in_phi0, in_phi1, in_th0, in_th1;   // the +-0.99 clip is inactive (clamp backward passes the gradient only there)
     PclTaps<FMT> ta, tb;  // gathers in flight (point .x, point .y)
+    unsigned zq0, zq1;    // DEPTH only: the z-buffer cells of the two points (squared-depth bit patterns), in flight
 };
+
+// cell indices of two points from their angles, make_pano's formula (utils.py:158-165) on the Hd x Wd grid:
+//   col = trunc((gx + 1) / 2 (Wd - 1)),  (gx + 1) / 2 = 1/2 - phi / (2 pi)            (gx = -phi / pi)
+//   row = trunc((gy + 1) / 2 (Hd - 1)),  (gy + 1) / 2 = 1/2 - 4 hel / (2 pi)          (gy = 2 theta / pi - 1, theta = pi/2 - 2 hel)
+// 1/2, 4 and 1/(2 pi) are inline constants of the ISA: the only scalar registers this needs are Wd - 1, Hd - 1 and Wd.  No clamp:
+// phi in [-pi, pi] and hel in [-pi/4, pi/4] keep col in [0, Wd - 1] and row in [0, Hd - 1] (rounding at the ends truncates
+// inwards, a NaN angle converts to 0), and the z-buffer is read through a bounds-checked buffer resource.
+__device__ __forceinline__ void pcl_depth_cells2(f2 phi, f2 hel, const PclDepthGrid& g, int& row0, int& col0, int& row1, int& col1)
+{
+    const float inv_2pi = 0.15915494309189532f;
+    f2 colf = pcl_fma2(-phi, F2(inv_2pi), F2(0.5f)) * F2(g.wm1);
+    f2 rowf = pcl_fma2(-(hel * F2(4.0f)), F2(inv_2pi), F2(0.5f)) * F2(g.hm1);
+    row0 = (int)rowf.x; col0 = (int)colf.x; row1 = (int)rowf.y; col1 = (int)colf.y;
+}
 
 // q = x - t ; p = R q for two points (packed)                               (omniloc.py:190-191, :332-338)
 // The pose is six 64-bit SGPR pairs (R0,R1)(R2,R3)(R4,R5)(R6,R7)(R8,t0)(t1,t2) and every scalar is broadcast to both
@@ -253,40 +268,60 @@ __device__ __forceinline__ void pcl_rotate2(f2 x, f2 y, f2 z, const PclPoseRec* 
 }
 
 // Phase A: q = x - t, p = R q, cloud2idx, clip, pixel + fractions, issue the gathers.
-template <int FMT>
-__device__ __forceinline__ void pcl_project2_rotated(__amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o);
+template <int FMT, bool DEPTH = false>
+__device__ __forceinline__ void pcl_project2_rotated(__amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o,
+                                                     __amdgpu_buffer_rsrc_t zb = __amdgpu_buffer_rsrc_t(), int zoff = 0,
+                                                     const PclDepthGrid* dg = nullptr);
 
-template <int FMT>
+template <int FMT, bool DEPTH = false>
 __device__ __forceinline__ void pcl_project2(f2 x, f2 y, f2 z, const PclPose6& pose,
-                                             __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
+                                             __amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o,
+                                             __amdgpu_buffer_rsrc_t zb = __amdgpu_buffer_rsrc_t(), int zoff = 0, const PclDepthGrid* dg = nullptr)
 {
     pcl_rotate2(x, y, z, pose, o.px, o.py, o.pz);
-    pcl_project2_rotated<FMT>(tex, dm, o);
+    pcl_project2_rotated<FMT, DEPTH>(tex, dm, o, zb, zoff, dg);
 }
 
-// (o.px, o.py, o.pz already hold p = R (x - t))
-template <int FMT>
-__device__ __forceinline__ void pcl_project2_rotated(__amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o)
+// cloud2idx's two angles for two camera-frame points (utils.py:44-59): phi = atan2(py, px + eps) and HALF the elevation
+// e = atan2(pz + eps, rho), plus the by-products the gradient reuses.  Shared by the loss / trim kernels and the depth passes
+// (csrc/pcl_depth.hip), which must land a point in the same z-buffer cell as the loss kernel's lookup.
+__device__ __forceinline__ void pcl_angles2(f2 px, f2 py, f2 pz, f2& rho2, f2& rinv, f2& rs2, f2& phi, f2& half_el)
 {
     // cloud2idx (utils.py:44-59): gx = 1 - (atan2(py, a) + pi)/pi = -phi/pi ; gy = 2 theta/pi - 1
-    f2 a = o.px + F2(1e-6f), b = o.pz + F2(1e-6f);
-    o.rho2 = pcl_fma2(o.px, o.px, o.py * o.py);
+    f2 a = px + F2(1e-6f), b = pz + F2(1e-6f);
+    rho2 = pcl_fma2(px, px, py * py);
     // 1/rho; rho = 0 gives rho2 * rinv = 0 and a zero gradient through rho (norm backward is 0 at 0)
     // (+1e-37: exact no-op for any normal rho2, keeps rsq finite at 0; one packed add instead of two v_max)
-    f2 rg = o.rho2 + F2(1e-37f);
-    o.rinv = (f2){__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
-    f2 rho = o.rho2 * o.rinv;
-    f2 phi = pcl_atan2_2(o.py, a);
+    f2 rg = rho2 + F2(1e-37f);
+    rinv = (f2){__builtin_amdgcn_rsqf(rg.x), __builtin_amdgcn_rsqf(rg.y)};
+    f2 rho = rho2 * rinv;
+    phi = pcl_atan2_2(py, a);
     // Elevation e = atan2(b, rho) (theta = pi/2 - e) by the half-angle form  e = 2 atan(b / (r + rho)),  r = sqrt(rho^2 + b^2):
     // rho >= 0, so |b| <= r + rho and the argument is in [-1, 1] for every point — no octant swap, no reflection, no sign
     // transfer (the octant form spent a min, a max3, a compare, a select and a v_bfi per point here), and its rsq is the one
     // the gradient needs anyway (1 / s2 = rs2^2 instead of a v_rcp): 4.5 VALU instructions and one transcendental less per
     // point-pose.  The polynomial's 8.7e-8 error is doubled: 1.7e-7 rad, below the fp32 ulp of the row coordinate.
     // (+1e-37: keeps rsq and the quotient finite for a point AT the camera centre shifted by -eps; exact no-op otherwise.)
-    f2 s2 = pcl_fma2(b, b, o.rho2) + F2(1e-37f);
-    o.rs2 = (f2){__builtin_amdgcn_rsqf(s2.x), __builtin_amdgcn_rsqf(s2.y)};
-    f2 den = pcl_fma2(s2, o.rs2, rho);
-    f2 half_el = pcl_atan_poly2(b * (f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
+    f2 s2 = pcl_fma2(b, b, rho2) + F2(1e-37f);
+    rs2 = (f2){__builtin_amdgcn_rsqf(s2.x), __builtin_amdgcn_rsqf(s2.y)};
+    f2 den = pcl_fma2(s2, rs2, rho);
+    half_el = pcl_atan_poly2(b * (f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)});
+}
+
+// (o.px, o.py, o.pz already hold p = R (x - t))
+// DEPTH: also issue the look-ups of the two points' z-buffer cells (zb: this pose's z-buffer through a buffer resource)
+template <int FMT, bool DEPTH>
+__device__ __forceinline__ void pcl_project2_rotated(__amdgpu_buffer_rsrc_t tex, const PclDims& dm, PclProj<FMT>& o, __amdgpu_buffer_rsrc_t zb,
+                                                     int zoff, const PclDepthGrid* dg)
+{
+    f2 phi, half_el;
+    pcl_angles2(o.px, o.py, o.pz, o.rho2, o.rinv, o.rs2, phi, half_el);
+    if constexpr (DEPTH) {
+        int r0, c0, r1, c1;
+        pcl_depth_cells2(phi, half_el, *dg, r0, c0, r1, c1);
+        o.zq0 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(zb, (int)(__umul24((unsigned)r0, (unsigned)dg->Wd) + (unsigned)c0) * 4, zoff, 0);
+        o.zq1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(zb, (int)(__umul24((unsigned)r1, (unsigned)dg->Wd) + (unsigned)c1) * 4, zoff, 0);
+    }
     // sample_from_img (utils.py:97-98): g = (-phi/pi, -2 elev/pi) clipped to +-0.99, unnormalised (align_corners=False),
     // +1 for the zero border.  The clip is applied to the angles (|phi| <= 0.99 pi, |elev| <= 0.495 pi: the same set up to
     // the last ulp of the threshold) so the pixel coordinate is one fma from the angle.

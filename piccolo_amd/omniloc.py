@@ -13,10 +13,10 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
   * omniloc_batch also accepts a single candidate (the reference asserts num_input > 1, omniloc.py:208; the assert
     is kept because callers may rely on it, see `strict_reference_asserts`);
   * extra, optional cfg keys: depth_mask (default False = reference behaviour) multiplies the north star's
-    scatter-min visibility (csrc/pcl_depth.hip) into the loss mask, depth_tau is its tolerance; depth_refresh_t (metres) /
-    depth_refresh_r (radians), default 0: a candidate's mask is recomputed only when its forward pose has left that bound
-    around the pose the mask in use was computed for (0: always the current pose's mask; include/piccolo_hip.h states the bound);
-    depth_every = k (default 1): and only when the mask in use has served k loss passes (every k-th iteration with bounds 0);
+    scatter-min visibility (csrc/pcl_depth.hip) of the CURRENT poses into the loss mask at every iteration; depth_res =
+    (depth_h, depth_w) is the z-buffer's grid (default: by point density, pcl_depth_default — not the panorama's size),
+    depth_tau its tolerance (default: the rule's value for the grid), depth_stride = s builds the z-buffer from every s-th
+    point of the Morton-ordered cloud (default: pcl_depth_default's choice; every point is still tested against it);
   * cfg.visualize: the reference's frame capture is broken (`new_xyz` undefined, omniloc.py:61 -> NameError); here
     omniloc returns the frame list that code means to build (query image over the cloud rendered at the current pose,
     per iteration) as 4th element.
@@ -166,9 +166,9 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
     p0 = panos[0]
     num_iter = _cfg(cfg, "num_iter", 100)
     depth = bool(_cfg(cfg, "depth_mask", False))
+    d_tau, d_res, d_st = _cfg(cfg, "depth_tau", None), _cfg(cfg, "depth_res", None), _cfg(cfg, "depth_stride", None)
     hyper = (float(_cfg(cfg, "lr", 0.1)), int(_cfg(cfg, "patience", 5)), float(_cfg(cfg, "factor", 0.9)), bool(batch_mode), depth,
-             float(_cfg(cfg, "depth_tau", 0.02)), float(_cfg(cfg, "depth_refresh_t", 0.0)), float(_cfg(cfg, "depth_refresh_r", 0.0)),
-             int(_cfg(cfg, "depth_every", 1)))
+             None if d_tau is None else float(d_tau), None if d_res is None else (int(d_res[0]), int(d_res[1])), None if d_st is None else int(d_st))
     use_graph = _cfg(cfg, "gd_graph", None)
     if use_graph is None and os.environ.get("PCL_GD_GRAPH") in ("0", "1"):          # experiments
         use_graph = os.environ["PCL_GD_GRAPH"] == "1"
@@ -178,7 +178,7 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
 
     def make(c=cloud, bx=box):
         return ops.GradientDescent(c, p0, trans, rot, bx, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
-                                   depth_mask=hyper[4], depth_tau=hyper[5], depth_refresh_t=hyper[6], depth_refresh_r=hyper[7], depth_every=hyper[8])
+                                   depth_mask=hyper[4], depth_tau=hyper[5], depth_res=hyper[6], depth_stride=hyper[7])
     if not use_graph:
         gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
     else:
@@ -349,11 +349,20 @@ def sampling_loss(img, xyz, rgb, input_trans, input_rot, starting_point, cfg, re
     """Forward-only loss of one starting pose — omniloc.py:105-157."""
     cloud, pano = packed_cloud(xyz, rgb), packed_pano(img)
     t, r = input_trans[starting_point], input_rot[starting_point]
-    res = ops.sampling_loss(cloud, pano, t, r, with_grad=False)[0]
+    res = ops.sampling_loss(cloud, pano, t, r, with_grad=False, depth=_depth_cfg(cfg))[0]
     loss = res[0].cpu()
     if return_list:
         return [t.detach().reshape(3, 1).cpu().clone(), _rot_matrix(ops._dev(r)).cpu(), loss]
     return loss
+
+
+def _depth_cfg(cfg):
+    """None (the reference's loss), or the depth-mask arguments of ops.sampling_loss from cfg.depth_mask / depth_res / depth_tau —
+    the same mask one iteration of the GD loop uses for these poses."""
+    if not bool(_cfg(cfg, "depth_mask", False)):
+        return None
+    return {"depth_res": _cfg(cfg, "depth_res", None), "depth_tau": _cfg(cfg, "depth_tau", None), "depth_stride": _cfg(cfg, "depth_stride", None),
+            "on": True}
 
 
 # ------------------------------------------------------------------------------------------------ nn.Modules
@@ -361,8 +370,8 @@ class _LossFn(torch.autograd.Function):
     """loss_b(t_b, ypr_b) for B poses; the fused kernel returns loss and gradient together, backward just scales."""
 
     @staticmethod
-    def forward(ctx, cloud, pano, trans, rot):
-        res = ops.sampling_loss(cloud, pano, trans, rot, with_grad=True)
+    def forward(ctx, cloud, pano, trans, rot, depth=None):
+        res = ops.sampling_loss(cloud, pano, trans, rot, with_grad=True, depth=depth)
         ctx.save_for_backward(res[:, 2:5], res[:, 5:8])
         ctx.devs = (trans.device, rot.device)
         return res[:, 0].to(trans.device)
@@ -371,7 +380,7 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, grad_loss):
         gt, gr = ctx.saved_tensors
         g = grad_loss.to(gt.device).reshape(-1, 1)
-        return None, None, (g * gt).to(ctx.devs[0]), (g * gr).to(ctx.devs[1])
+        return None, None, (g * gt).to(ctx.devs[0]), (g * gr).to(ctx.devs[1]), None
 
 
 class SamplingLoss(nn.Module):
@@ -385,7 +394,7 @@ class SamplingLoss(nn.Module):
     def forward(self, translation, yaw, pitch, roll):
         trans = translation.reshape(1, 3)
         rot = torch.cat([yaw.reshape(1), pitch.reshape(1), roll.reshape(1)]).reshape(1, 3)
-        return _LossFn.apply(self._cloud, self._pano, trans, rot)[0]
+        return _LossFn.apply(self._cloud, self._pano, trans, rot, _depth_cfg(self.cfg))[0]
 
 
 class BatchSamplingLoss(nn.Module):
@@ -404,5 +413,5 @@ class BatchSamplingLoss(nn.Module):
             raise RuntimeError("BatchSamplingLoss: batch size %d != cfg.num_input %d" % (B, self.num_input))
         trans = translation.reshape(B, 3)
         rot = torch.cat([yaw.reshape(B, 1), pitch.reshape(B, 1), roll.reshape(B, 1)], dim=1)
-        loss_list = _LossFn.apply(self._cloud, self._pano, trans, rot)
+        loss_list = _LossFn.apply(self._cloud, self._pano, trans, rot, _depth_cfg(self.cfg))
         return loss_list.sum(), loss_list

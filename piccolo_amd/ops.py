@@ -149,14 +149,61 @@ def _known_levels(img):
     return tag is not None and torch.is_tensor(img) and tag == img._version and os.environ.get("PCL_VERIFY_LEVELS") != "1"
 
 
-def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None):
-    """(B, 8) float tensor on the GPU: loss, count, dL/dt(3), dL/d(yaw, pitch, roll)."""
+def default_depth(n, H, W, stride=0):
+    """(depth_h, depth_w, tau, stride) of pcl_depth_default: the scatter-min depth mask's grid, tolerance and occluder stride for an
+    n-point cloud seen in an H x W panorama (>= 12 occluder samples per cell, never finer than the panorama; tau = 3.5 pi / depth_h
+    in [0.02, 0.15]; stride 0: the largest of 1, 2, 4 that keeps depth_h >= 128)."""
+    dh, dw, tau, st = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0), ctypes.c_int(0)
+    _lib.check(_lib.load().pcl_depth_default(int(n), int(H), int(W), int(stride), ctypes.byref(dh), ctypes.byref(dw), ctypes.byref(tau),
+                                             ctypes.byref(st)), "pcl_depth_default")
+    return dh.value, dw.value, tau.value, st.value
+
+
+def default_depth_res(n, H, W, stride=0):
+    return default_depth(n, H, W, stride)[:2]
+
+
+def depth_tau_rule(depth_h):
+    """the tolerance pcl_depth_default attaches to a grid of depth_h rows"""
+    return min(max(3.5 * 3.141592653589793 / max(int(depth_h), 1), 0.02), 0.15)
+
+
+def _depth_args(n, H, W, depth_res, depth_tau, depth_stride=None):
+    """(depth_h, depth_w, tau, stride) from the optional cfg values: missing pieces come from pcl_depth_default; a given grid
+    without a tolerance gets the rule's tolerance FOR THAT GRID, without a stride every point builds the z-buffer."""
+    if depth_res is None:
+        dh, dw, tau, st = default_depth(n, H, W, int(depth_stride or 0))
+    else:
+        dh, dw = int(depth_res[0]), int(depth_res[1])
+        tau, st = depth_tau_rule(dh), int(depth_stride or 1)
+    if depth_tau is not None:
+        tau = float(depth_tau)
+    return dh, dw, float(tau), st
+
+
+def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None, depth=None):
+    """(B, 8) float tensor on the GPU: loss, count, dL/dt(3), dL/d(yaw, pitch, roll).
+    visible: (B, n) uint8 mask in packed point order.  depth: True, or a dict with optional depth_res / depth_tau / depth_stride — the
+    scatter-min depth mask of the SAME poses is built and looked up inside the launch (pcl_sampling_loss_depth)."""
     lib = _lib.load()
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
     B = int(trans.shape[0])
     if rot.shape[0] != B:
         raise ValueError("trans and rot must have the same number of rows")
     out = torch.empty(B, _lib.RESULT_STRIDE, dtype=F32, device=trans.device)
+    if depth:
+        if visible is not None:
+            raise ValueError("sampling_loss: pass either a byte mask (visible) or depth, not both")
+        d = depth if isinstance(depth, dict) else {}
+        dh, dw, tau, st = _depth_args(cloud.n, pano.H, pano.W, d.get("depth_res"), d.get("depth_tau"), d.get("depth_stride"))
+        ws_bytes = lib.pcl_loss_depth_workspace_bytes(cloud.n, B, pano.H, pano.W, dh, dw)
+        if ws_bytes == 0:
+            raise _lib.PiccoloHipError("pcl_loss_depth_workspace_bytes: invalid depth grid %dx%d" % (dh, dw))
+        ws = _bytes(ws_bytes)
+        _lib.check(lib.pcl_sampling_loss_depth(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(trans), _ptr(rot), B,
+                                               1 if with_grad else 0, dh, dw, tau, st, _ptr(out), _ptr(ws), ws_bytes, _stream()),
+                   "pcl_sampling_loss_depth")
+        return out
     ws_bytes = lib.pcl_loss_workspace_bytes(cloud.n, B)
     ws = _bytes(ws_bytes)
     vis = None
@@ -352,15 +399,19 @@ def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
     return scores
 
 
-def depth_mask(cloud, trans, rot, resolution, tau=0.02):
-    """(B, n) uint8 GPU tensor in PACKED point order: scatter-min visibility of every point for every pose."""
+def depth_mask(cloud, trans, rot, resolution, tau=None, stride=1):
+    """(B, n) uint8 GPU tensor in PACKED point order: scatter-min visibility of every point for every pose on a z-buffer grid of
+    `resolution` = (depth_h, depth_w) cells (the DEPTH grid — see default_depth — not the panorama's size) built from every
+    stride-th packed point; tau None: the rule's tolerance for that grid."""
     lib = _lib.load()
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
     B, (H, W) = int(trans.shape[0]), (int(resolution[0]), int(resolution[1]))
+    if tau is None:
+        tau = depth_tau_rule(H)
     vis = torch.empty(B, cloud.n, dtype=torch.uint8, device=trans.device)
     nws = lib.pcl_depth_workspace_bytes(B, H, W)
     ws = _bytes(nws)
-    _lib.check(lib.pcl_depth_mask(_ptr(cloud.data), cloud.n, _ptr(trans), _ptr(rot), B, H, W, float(tau), _ptr(vis), _ptr(ws), nws,
+    _lib.check(lib.pcl_depth_mask(_ptr(cloud.data), cloud.n, _ptr(trans), _ptr(rot), B, H, W, float(tau), int(stride), _ptr(vis), _ptr(ws), nws,
                                   _stream()), "pcl_depth_mask")
     return vis
 
@@ -451,16 +502,19 @@ class GradientDescent:
     """On-device GD refinement of B candidates (Adam + ReduceLROnPlateau + clamp), pcl_gd_* of the C ABI."""
 
     def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True, depth_mask=False,
-                 depth_tau=0.02, depth_refresh_t=0.0, depth_refresh_r=0.0, depth_every=1):
+                 depth_tau=None, depth_res=None, depth_stride=None):
         lib = _lib.load()
         self.cloud, self.pano = cloud, pano
         trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
         self.B = int(trans.shape[0])
         self.box = _dev(box).reshape(6)
+        dh, dw, tau, st = _depth_args(cloud.n, pano.H, pano.W, depth_res, depth_tau, depth_stride) if depth_mask else (0, 0, 0.0, 0)
         self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL,
-                                  1 if depth_mask else 0, float(depth_tau), float(depth_refresh_t), float(depth_refresh_r), int(depth_every), 0)
+                                  1 if depth_mask else 0, float(tau), int(dh), int(dw), int(st), 0)
         self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
         self.ws_bytes = lib.pcl_gd_workspace_bytes(cloud.n, self.B, pano.H, pano.W, ctypes.byref(self.hyper))
+        if self.ws_bytes == 0:
+            raise _lib.PiccoloHipError("pcl_gd_workspace_bytes: invalid arguments (depth grid %dx%d?)" % (dh, dw))
         self.ws = _bytes(self.ws_bytes)
         _lib.check(lib.pcl_gd_init(_ptr(self.state), _ptr(trans), _ptr(rot), self.B, ctypes.byref(self.hyper), _stream()),
                    "pcl_gd_init")
@@ -553,15 +607,16 @@ class GradientDescent:
                    "pcl_gd_winner")
         return out
 
-    def depth_refresh_counts(self):
-        """(B,) int32 GPU tensor: how many times each candidate's depth mask has been computed since the last init / reset."""
-        out = torch.zeros(self.B, dtype=torch.int32, device=self.state.device)
-        if self.hyper.depth_mask:
-            _lib.check(_lib.load().pcl_gd_depth_refresh_counts(_ptr(self.state), self.B, _ptr(out), _stream()), "pcl_gd_depth_refresh_counts")
-        return out
+    def step_from_grads(self, loss, grad):
+        """Teacher-forcing hook (tests): ONE optimiser step of every candidate from a GIVEN loss (B,) and gradient (B, 6) =
+        dL/d(t0, t1, t2, yaw, pitch, roll) through the epilogue's own Adam / ReduceLROnPlateau / clamp code (pcl_gd_step_from_grads)."""
+        loss, grad = _dev(loss).reshape(self.B), _dev(grad).reshape(self.B, 6)
+        scratch = torch.empty(self.B * 8, dtype=F32, device=self.state.device)
+        _lib.check(_lib.load().pcl_gd_step_from_grads(_ptr(self.state), self.B, _ptr(loss), _ptr(grad), _ptr(self.box), ctypes.byref(self.hyper),
+                                                      _ptr(scratch), _stream()), "pcl_gd_step_from_grads")
 
     def result(self):
-        """(B, 14): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr."""
+        """(B, 16): fwd t(3), fwd ypr(3), leaf t(3), leaf ypr(3), last loss, lr, scheduler num_bad_epochs, scheduler best."""
         lib = _lib.load()
         out = torch.empty(self.B, _lib.GD_RESULT_STRIDE, dtype=F32, device=self.state.device)
         _lib.check(lib.pcl_gd_result(_ptr(self.state), self.B, _ptr(out), _stream()), "pcl_gd_result")

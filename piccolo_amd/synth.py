@@ -89,6 +89,28 @@ def inside_furniture(t, margin=0.3):
     return any(all(abs(float(t[k]) - c[k]) <= sz[k] / 2 + margin for k in range(3)) for c, sz in _FURNITURE)
 
 
+def occluded_by_furniture(xyz, t, eps=1e-4):
+    """(n,) bool, float64 slab test: the open segment from camera position t to xyz[i] crosses the interior of one of
+    furnished_room's boxes — the ANALYTIC occlusion a depth mask is measured against (walls / floor behind furniture and the
+    faces of a box that point away from the camera; the room itself is convex and hides nothing)."""
+    P = np.asarray(xyz, np.float64)
+    t = np.asarray(t, np.float64).reshape(3)
+    d = P - t[None, :]
+    out = np.zeros(len(P), bool)
+    for c, sz in _FURNITURE:
+        lo, hi = np.array(c) - np.array(sz) / 2, np.array(c) + np.array(sz) / 2
+        with np.errstate(divide="ignore", invalid="ignore"):
+            s0, s1 = (lo[None, :] - t[None, :]) / d, (hi[None, :] - t[None, :]) / d
+        smin, smax = np.minimum(s0, s1), np.maximum(s0, s1)
+        par = d == 0                                                  # parallel to a slab: inside it for every s, or never
+        inside = (t[None, :] > lo[None, :]) & (t[None, :] < hi[None, :])
+        smin = np.where(par, np.where(inside, -np.inf, np.inf), smin)
+        smax = np.where(par, np.where(inside, np.inf, -np.inf), smax)
+        enter, leave = smin.max(axis=1), smax.min(axis=1)
+        out |= np.maximum(enter, 0.0) < np.minimum(leave, 1.0 - eps) - eps       # a piece of positive length strictly before the point
+    return out
+
+
 def gt_pose(seed):
     """Ground-truth (t (3,), ypr (3,)) for query image `seed`: t in the central half of the room."""
     rng = np.random.default_rng(10_000 + seed)

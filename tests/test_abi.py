@@ -60,8 +60,8 @@ def test_size_queries_and_argument_checks(lib):
     assert lib.pcl_cloud_bytes(1000) == 1024 * 6 * 4
     assert lib.pcl_pano_bytes(4, 8, _lib.PANO_F32) == 6 * 10 * 16 and lib.pcl_pano_bytes(4, 8, _lib.PANO_U8) == 6 * 10 * 4 and lib.pcl_pano_bytes(4, 8, _lib.PANO_F16) == 6 * 10 * 8
     assert lib.pcl_pano_bytes(4, 8, 7) == 0 and lib.pcl_pano_bytes(0, 8, 0) == 0
-    # two copies (fused iterations read one while they write the other) + the 48-byte depth-mask refresh record per candidate
-    assert lib.pcl_gd_state_bytes(32) == 2 * 32 * (160 + 64) + 32 * 48
+    # two copies (fused iterations read one while they write the other); the depth mask keeps nothing in the state (ABI 7)
+    assert lib.pcl_gd_state_bytes(32) == 2 * 32 * (160 + 64)
     ws1, ws2 = lib.pcl_loss_workspace_bytes(1_000_000, 32), lib.pcl_loss_workspace_bytes(1_000_000, 256)
     assert 0 < ws1 < ws2 < 64 << 20
     assert lib.pcl_loss_workspace_bytes(0, 32) == 0
@@ -135,6 +135,46 @@ def test_every_entry_point_rejects_null_arguments_before_touching_a_device():
     assert not wrong, wrong
     # handle-returning / void functions: called with nulls above without a crash, nothing to compare
     assert set(skipped) <= {"pcl_timer_create", "pcl_timer_destroy", "pcl_timer_reset", "pcl_timer_set_stride"}, skipped
+
+
+def test_depth_default_grid_and_tolerance_host_only():
+    """pcl_depth_default (host-only): >= 12 occluder samples per cell, depth_w = 2 depth_h, a multiple of 8, never finer than the
+    panorama; tau = 3.5 pi / depth_h in [0.02, 0.15]; the occluder stride: the largest of 1, 2, 4 that keeps depth_h >= 128
+    (tools/depth_recall.py: what recall / precision that buys); and the workspace sizes that follow from it."""
+    import ctypes
+    import math
+    from piccolo_amd import _lib
+    lib = _lib.load()
+
+    def dflt(n, H, W, stride=0):
+        h, w, t, st = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_float(0), ctypes.c_int(0)
+        assert lib.pcl_depth_default(n, H, W, stride, ctypes.byref(h), ctypes.byref(w), ctypes.byref(t), ctypes.byref(st)) == 0
+        return h.value, w.value, t.value, st.value
+    for n, H, W in ((1_000_000, 1024, 2048), (166_667, 1024, 2048), (10_000_000, 2048, 4096), (40_000, 128, 256), (100_000, 256, 512)):
+        for stride in (0, 1, 2):
+            h, w, t, st = dflt(n, H, W, stride)
+            assert st == stride or stride == 0
+            m = (n + st - 1) // st                                     # occluder samples
+            assert w == 2 * h and h % 8 == 0 and h <= H and w <= W
+            assert m / (h * w) >= 12 and m / ((h + 8) * 2 * (h + 8)) < 12, (n, st, h, w)
+            assert abs(t - min(max(3.5 * math.pi / h, 0.02), 0.15)) < 1e-6
+            if stride == 0:
+                assert st in (1, 2, 4) and (st == 1 or h >= 128) and (st == 4 or dflt(n, H, W, 2 * st)[0] < 128), (n, st, h)
+    assert dflt(1_000_000, 1024, 2048, 1)[:2] == (200, 400)         # every point: make_pano's own default resolution (utils.py:134)
+    assert dflt(1_000_000, 1024, 2048) == (144, 288, dflt(1_000_000, 1024, 2048)[2], 2)
+    assert dflt(166_667, 1024, 2048)[3] == 1 and dflt(10_000_000, 2048, 4096)[3] == 4
+    assert dflt(1_000_000, 64, 128)[:2] == (64, 128)                # never finer than the panorama
+    assert lib.pcl_depth_default(1000, 64, 128, 0, None, None, None, None) == 0 and lib.pcl_depth_default(0, 64, 128, 0, None, None, None, None) == -1
+    hyper = _lib.GdHyper(0.1, 0.8, 5, _lib.GD_BATCH, 0, 0.0, 0, 0, 0, 0)
+    plain = lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper))
+    hyper.depth_mask = 1
+    masked = lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper))
+    assert 0 < plain < masked and masked - plain == 2 * 32 * 144 * 288 * 4       # two sets of 5.3 MB of z-buffers (round 4: 268 MB + 32 MB of byte masks)
+    hyper.depth_h, hyper.depth_w = 1024, 2048
+    assert lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper)) - plain == 2 * 32 * 1024 * 2048 * 4
+    hyper.depth_h, hyper.depth_w = 200, 0                           # half a grid: invalid
+    assert lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper)) == 0
+    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 0, 0) > lib.pcl_loss_workspace_bytes(1_000_000, 32)
 
 
 def test_gd_plan_reports_the_decomposition_host_only():

@@ -411,6 +411,60 @@ def test_gd_epilogue_teacher_forced_single_steps(ops, oracle, parity):
     parity("one Adam step, angles vs oracle optimiser (abs)", np.abs(res[:, 9:12] - ir).max(), 2e-7)
 
 
+@pytest.mark.parametrize("tag", ["seq0_", "seq1_", "bat_", "bat1_", "bat2_"])
+def test_device_optimiser_teacher_forced_all_iterations(ops, parity, tag):
+    """SURVEY section 4 item 3 on the DEVICE: the optimiser code of the GD epilogue — torch.optim.Adam,
+    ReduceLROnPlateau, the clamp in both modes incl. the batch path's clamp lag, the next forward pose — driven for all 100
+    iterations by the reference's OWN recorded loss_list and autograd gradients (G5: omniloc.py:253-258 wrapped by the golden
+    generator), one pcl_gd_step_from_grads per iteration: the pose every forward sees and the leaf Adam updates within 1e-6 of the
+    reference's at EVERY step, lr / num_bad_epochs / best exactly the reference's after every scheduler step.  A wrong beta2_pow at
+    step 50 fails here (the free-running tests could not see it).  bat1 / bat2: the start outside the clamp box."""
+    g = load_golden("g5_trajectories.npz")
+    cfg = Cfg(**json.loads(str(g["cfg"])))
+    batch = tag.startswith("bat")
+    rows = slice(None) if batch else slice(int(tag[3]), int(tag[3]) + 1)
+    trans0, rot0 = g["trans0"][rows], g["rot0"][rows]
+    n_it = g[tag + "fwd_loss"].shape[0]
+    cloud, pano = ops.Cloud(T(g["xyz"]), T(g["rgb"])), ops.Pano(T(g["img"]))
+    box = ops.quantile_box(T(g["xyz"]), cfg.out_of_room_quantile)
+    gd = ops.GradientDescent(cloud, pano, T(trans0), T(rot0), box, lr=cfg.lr, patience=cfg.patience, factor=cfg.factor, batch_mode=batch)
+    worst_fwd = worst_leaf = 0.0
+    for k in range(n_it):
+        res = gd.result().cpu().numpy()
+        # the pose forward k sees (omniloc.py:253) and the leaf Adam is about to update (Adam order t, yaw, roll, pitch)
+        worst_fwd = max(worst_fwd, float(np.abs(res[:, 0:3] - g[tag + "fwd_trans"][k]).max()), float(np.abs(res[:, 3:6] - g[tag + "fwd_rot"][k]).max()))
+        pb = g[tag + "adam_param_before"][k]
+        leaf_ref = np.stack([pb[:, 0], pb[:, 1], pb[:, 2], pb[:, 3], pb[:, 5], pb[:, 4]], 1)
+        worst_leaf = max(worst_leaf, float(np.abs(res[:, 6:12] - leaf_ref).max()))
+        assert np.array_equal(res[:, 13], g[tag + "adam_lr"][k].astype(np.float32)), (k, res[:, 13], g[tag + "adam_lr"][k])
+        ag = g[tag + "adam_grad"][k]
+        grad = np.stack([ag[:, 0], ag[:, 1], ag[:, 2], ag[:, 3], ag[:, 5], ag[:, 4]], 1).astype(np.float32)     # -> t, yaw, pitch, roll
+        gd.step_from_grads(T(g[tag + "fwd_loss"][k].astype(np.float32)), T(grad))
+        res = gd.result().cpu().numpy()
+        assert np.array_equal(res[:, 13], g[tag + "sched_lr"][k].astype(np.float32)), (k, res[:, 13], g[tag + "sched_lr"][k])
+        assert np.array_equal(res[:, 14], g[tag + "sched_num_bad"][k].astype(np.float32)), (k, res[:, 14], g[tag + "sched_num_bad"][k])
+        assert np.array_equal(res[:, 15], g[tag + "sched_best"][k].astype(np.float32)), (k, res[:, 15], g[tag + "sched_best"][k])
+        assert np.array_equal(res[:, 12], g[tag + "fwd_loss"][k].astype(np.float32)), k            # "last loss" = the loss it was stepped with
+        if batch:
+            # the post-step parameters as Adam left them, BEFORE the clamp = what the next forward sees in batch mode
+            pa = g[tag + "adam_param_after"][k]
+            after_ref = np.stack([pa[:, 0], pa[:, 1], pa[:, 2], pa[:, 3], pa[:, 5], pa[:, 4]], 1)
+            worst_fwd = max(worst_fwd, float(np.abs(res[:, 0:6] - after_ref).max()))
+    parity("%s teacher-forced on the device, %d iterations: forward pose vs the reference's (abs, worst step)" % (tag, n_it), worst_fwd, 1e-6)
+    parity("%s teacher-forced on the device: Adam's leaf vs the reference's (abs, worst step)" % tag, worst_leaf, 1e-6)
+    # what the reference returns / leaves in the caller's rows
+    res = gd.result().cpu().numpy()
+    out = gd.winner(1).cpu().numpy()[0] if batch else None
+    if batch:
+        assert np.abs(out[0:3] - g[tag + "ret_t"].reshape(3)).max() <= 1e-6 and np.abs(out[3:12].reshape(3, 3) - g[tag + "ret_R"]).max() <= 1e-6
+        assert abs(out[12] - float(g[tag + "ret_loss"])) <= 1e-7
+        assert np.abs(res[:, 6:9] - g[tag + "input_trans_after"]).max() <= 1e-6 and np.abs(res[:, 9:12] - g[tag + "input_rot_after"]).max() <= 1e-6
+    else:
+        sp = int(tag[3])
+        assert np.abs(res[0, 0:3] - g[tag + "ret_t"].reshape(3)).max() <= 1e-6
+        assert np.abs(res[0, 6:9] - g[tag + "input_trans_after"][sp]).max() <= 1e-6 and np.abs(res[0, 9:12] - g[tag + "input_rot_after"][sp]).max() <= 1e-6
+
+
 # --------------------------------------------------------------------------------------- reference call surface
 def test_omniloc_batch_surface(ops, oracle):
     from piccolo_amd import omniloc as po
@@ -697,58 +751,101 @@ def test_large_batch_and_odd_batch(ops, oracle, parity):
             parity("B=%d forward only: loss vs fp64" % B, rel(out[:, 0], ref["loss"]), 3e-7 + 2.0 * dcount / n)
 
 
-def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle):
-    """The build-defined scatter-min depth mask (parity unpinned: no reference call site).  (1) The packed-cloud mask
-    equals the oracle's scatter-min + threshold up to pixel-boundary flips.  (2) With occluders in front of the walls
-    the mask actually hides points.  (3) cfg.depth_mask=True runs inside the on-device GD loop and still converges;
-    cfg.depth_mask=False is bit-identical to not passing the key."""
-    from piccolo_amd import omniloc as po
+def _occluder_scene(n=40_000):
+    """box room + a second, smaller box inside it that hides part of the walls from any viewpoint"""
     from piccolo_amd import synth
-    n, H, W, B, tau = 40_000, 128, 256, 3, 0.02
     xyz, rgb = synth.box_room(n, 17)
-    # occluders: a second, smaller box inside the room hides part of the walls from any viewpoint
     inner, inner_rgb = synth.box_room(n // 4, 18)
     xyz = np.concatenate([xyz, inner * 0.25 + np.array([1.5, 1.0, 0.0], np.float32)]).astype(np.float32)
     rgb = np.concatenate([rgb, inner_rgb]).astype(np.float32)
+    return xyz, rgb
+
+
+def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle, parity):
+    """The build-defined scatter-min depth mask (parity unpinned: no reference call site) on ITS OWN grid (round 5: depth_res, by
+    point density — not the panorama's).  (1) The byte mask of pcl_depth_mask equals the oracle's scatter-min + threshold on the same
+    grid up to cell-boundary flips, for the default grid, a finer one and the panorama's own resolution.  (2) The loss kernel's
+    in-kernel lookup (pcl_sampling_loss_depth: no byte mask) counts the same points as pcl_sampling_loss fed that byte mask — the z
+    pass and the lookup run the same instructions — and equals the oracle's masked loss.  (3) cfg.depth_mask=True runs inside the
+    on-device GD loop and still converges; cfg.depth_mask=False is bit-identical to not passing the key."""
+    from piccolo_amd import omniloc as po
+    from piccolo_amd import synth
+    n, H, W, B = 40_000, 128, 256, 4
+    xyz, rgb = _occluder_scene(n)
     t_gt, ypr_gt = synth.gt_pose(17)
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=17, sigma_t=0.1, sigma_r=0.05)
     cloud = ops.Cloud(T(xyz), T(rgb))
-    vis = ops.depth_mask(cloud, T(trans), T(rot), (H, W), tau=tau).cpu().numpy()
-    order = cloud.order.cpu().numpy()
-    assert vis.shape == (B, len(xyz))
-    for b in range(B):
-        cam = synth.transform_cloud(xyz, trans[b], rot[b])
-        zmin, _ = oracle.scatter_min_depth(cam, (H, W))
-        row, col = oracle.pano_pixels(cam, (H, W))
-        d = np.linalg.norm(cam.astype(np.float64), axis=1)
-        ref = d <= zmin[row.astype(np.int64) * W + col].astype(np.float64) * (1 + tau)
-        got = np.empty(len(xyz), bool)
-        got[order] = vis[b].astype(bool)                 # packed slot j holds original point order[j]
-        assert (got != ref).mean() <= 5e-3, (b, (got != ref).mean())
-        assert 0.05 < 1 - ref.mean() < 0.95              # the occluder really hides something
     img = oracle.make_pano_u8(synth.transform_cloud(xyz, t_gt, ypr_gt), rgb, (H, W)).astype(np.float32) / 255
+    pano = ops.Pano(T(img))
+    order = cloud.order.cpu().numpy()
+    dh, dw, dtau, dst = ops.default_depth(len(xyz), H, W)
+    assert (dh, dw, dst) == (40, 80, 1) and abs(dtau - 0.15) < 1e-6
+    # (64 x 128 and the panorama's own grid: the LDS-window z pass; the narrower ones: the coarse-tile cache; stride 2 / 3: the
+    #  z-buffer from every 2nd / 3rd point of the packed cloud, every point tested)
+    for (gh, gw), tau, stride in (((dh, dw), dtau, 1), ((64, 128), 0.05, 1), ((H, W), 0.02, 1), ((24, 40), 0.1, 1), ((64, 128), 0.08, 2), ((32, 64), 0.12, 3)):
+        vis = ops.depth_mask(cloud, T(trans), T(rot), (gh, gw), tau=tau, stride=stride).cpu().numpy()
+        assert vis.shape == (B, len(xyz))
+        ref_all = np.empty((B, len(xyz)), np.uint8)
+        for b in range(B):
+            cam = synth.transform_cloud(xyz, trans[b], rot[b])
+            zmin, _ = oracle.scatter_min_depth(cam[order[::stride]], (gh, gw))      # occluder samples: every stride-th PACKED point
+            zmin = np.where(zmin == 0, np.inf, zmin)                                # (torch_scatter's 0 for an empty cell: nothing in front)
+            row, col = oracle.pano_pixels(cam, (gh, gw))
+            d = np.linalg.norm(cam.astype(np.float64), axis=1)
+            ref = d <= zmin[row.astype(np.int64) * gw + col].astype(np.float64) * (1 + tau)
+            got = np.empty(len(xyz), bool)
+            got[order] = vis[b].astype(bool)                 # packed slot j holds original point order[j]
+            parity("depth mask %dx%d stride %d pose %d: share of points that differ from the oracle's mask" % (gw, gh, stride, b), float((got != ref).mean()), 5e-3)
+            assert 0.03 < 1 - ref.mean() < 0.95              # the occluder really hides something
+            ref_all[b] = ref
+        # (2) lookup inside the loss kernel == byte mask fed to the loss kernel: same cells, same comparisons
+        via_bytes = ops.sampling_loss(cloud, pano, T(trans), T(rot), visible=torch.from_numpy(vis).cuda()).cpu().numpy()
+        fused = ops.sampling_loss(cloud, pano, T(trans), T(rot), depth={"depth_res": (gh, gw), "depth_tau": tau, "depth_stride": stride}).cpu().numpy()
+        assert np.abs(fused[:, 1] - via_bytes[:, 1]).max() <= 2, (fused[:, 1], via_bytes[:, 1])       # (a contraction may differ by an ulp at a cell border)
+        parity("depth %dx%d: fused lookup vs byte mask, loss" % (gw, gh), rel(fused[:, 0], via_bytes[:, 0]), 2e-6)
+        parity("depth %dx%d: fused lookup vs byte mask, grad" % (gw, gh), rel(fused[:, 2:], via_bytes[:, 2:]), 2e-4)
+        o64 = oracle.sampling_loss(xyz, rgb, img, trans, rot, dtype=np.float64, grad=True, visible=ref_all)
+        flips = float(np.abs(fused[:, 1] - o64["count"]).max())
+        parity("depth %dx%d: masked count vs oracle (points)" % (gw, gh), flips, 5e-3 * len(xyz))
+        parity("depth %dx%d: masked loss vs fp64 oracle" % (gw, gh), rel(fused[:, 0], o64["loss"]), 3e-7 + 2.0 * flips / len(xyz))
+    # default arguments = the rule's grid and tolerance
+    a = ops.sampling_loss(cloud, pano, T(trans), T(rot), depth=True).cpu().numpy()
+    b_ = ops.sampling_loss(cloud, pano, T(trans), T(rot), depth={"depth_res": (dh, dw), "depth_tau": dtau, "depth_stride": dst}).cpu().numpy()
+    assert np.array_equal(a, b_)
     base = dict(lr=0.1, num_iter=60, patience=5, factor=0.8, out_of_room_quantile=0.05, num_input=B)
     X, C, I = T(xyz), T(rgb), T(img)
     r_off = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(**base), {})
     r_off2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=False, **base), {})
-    r_on = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=True, depth_tau=tau, **base), {})
+    r_on = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=True, **base), {})
+    r_on2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(depth_mask=True, depth_res=[dh, dw], depth_tau=dtau, depth_stride=dst, **base), {})
     assert all(torch.equal(a, b) for a, b in zip(r_off, r_off2))
+    assert all(torch.equal(a, b) for a, b in zip(r_on, r_on2))
     R_gt = synth.rot_from_ypr_np(ypr_gt)
     e_on = synth.pose_errors(r_on[0].numpy(), r_on[1].numpy(), t_gt, R_gt)
     e_off = synth.pose_errors(r_off[0].numpy(), r_off[1].numpy(), t_gt, R_gt)
     assert e_on[0] < 0.05 and e_on[1] < 1.0, (e_on, e_off)
     assert not torch.equal(r_on[0], r_off[0])            # the mask changed the objective
+    # the modules take the same cfg keys: loss and autograd gradient of the masked objective
+    m = po.BatchSamplingLoss(X, C, I, ops.device(), Cfg(depth_mask=True, **base))
+    tt = T(trans).reshape(B, 3, 1).clone().requires_grad_(True)
+    ang = [T(rot[:, k:k + 1]).clone().requires_grad_(True) for k in range(3)]
+    total, lst = m(tt, *ang)
+    total.backward()
+    assert np.allclose(lst.detach().cpu().numpy(), a[:, 0], rtol=1e-6) and np.allclose(tt.grad.reshape(B, 3).cpu().numpy(), a[:, 2:5], rtol=1e-5, atol=1e-7)
 
 
-def test_depth_mask_on_a_room_with_furniture(ops):
-    """What the mask is for (tools/furnished_room.py at bench size): in synth.furnished_room part of the walls is hidden behind
-    boxes from any pose; those points project into the query panorama and sample the furniture's colour.  At the ground-truth
-    pose the mask hides them (a few % of the cloud) and the loss of what remains is far lower; in the convex box room it hides
-    next to nothing."""
+def test_depth_mask_on_a_room_with_furniture(ops, parity):
+    """What the mask is for, measured against ANALYTIC occlusion (synth.occluded_by_furniture: the segment camera -> point crosses a
+    box): in synth.furnished_room ~20 % of the cloud is hidden from any pose (walls / floor behind the boxes, the boxes' far faces);
+    those points project into the query panorama and sample the colour of whatever is in front.  On the DEFAULT grid
+    (pcl_depth_default: >= 12 points per cell) the mask finds >= 90 % of them and >= 85 % of what it hides is truly occluded; on a
+    grid at the panorama's resolution — round 4's z-buffer — most cells hold one point and the mask finds a fraction.  The masked
+    loss at the ground-truth pose is far lower; in the convex box room the mask hides next to nothing that matters."""
     from piccolo_amd import synth
     n, H, W = 200_000, 512, 1024
     image_id = next(i for i in range(40) if not synth.inside_furniture(synth.gt_pose(i)[0]))
     t_gt, ypr_gt = synth.gt_pose(image_id)
+    dh, dw, dtau, dst = ops.default_depth(n, H, W)
     stats = {}
     for name, room in (("furnished", synth.furnished_room), ("box", synth.box_room)):
         xyz, rgb = room(n, 3)
@@ -757,28 +854,45 @@ def test_depth_mask_on_a_room_with_furniture(ops):
         img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W)))
         pano = ops.Pano(img)
         tg, rg = T(t_gt.reshape(1, 3)), T(ypr_gt.reshape(1, 3))
-        vis = ops.depth_mask(cloud, tg, rg, (H, W), tau=0.02)
+        vis = ops.depth_mask(cloud, tg, rg, (dh, dw), tau=dtau, stride=dst)
         plain = float(ops.sampling_loss(cloud, pano, tg, rg, with_grad=False)[0, 0])
-        masked = float(ops.sampling_loss(cloud, pano, tg, rg, with_grad=False, visible=vis)[0, 0])
+        masked = float(ops.sampling_loss(cloud, pano, tg, rg, with_grad=False, depth=True)[0, 0])
         stats[name] = (plain, masked, 1.0 - float(vis.float().mean()))
+        if name == "furnished":
+            occ = synth.occluded_by_furniture(xyz, t_gt)
+            order = cloud.order.cpu().numpy()
+
+            def scores(v):
+                hid = np.empty(n, bool)
+                hid[order] = ~v.cpu().numpy()[0].astype(bool)
+                tp = float((hid & occ).sum())
+                return tp / max(occ.sum(), 1), tp / max(hid.sum(), 1)
+            rec, prec = scores(vis)
+            rec_fine, prec_fine = scores(ops.depth_mask(cloud, tg, rg, (H, W), tau=0.02))
+            parity("furnished room, %d points, default depth grid %dx%d tau %.3f stride %d: 1 - recall vs analytic occlusion" % (n, dw, dh, dtau, dst), 1 - rec, 0.10)
+            parity("furnished room, %d points, default depth grid: 1 - precision" % n, 1 - prec, 0.15)
+            # the stride is a choice of occluder sampling, not of quality: at cfg-2 density (1M points: stride 2) the tool's table;
+            # here, forced on this 200k-point cloud, stride 2 on ITS grid stays within a few points of stride 1
+            h2, w2, t2, s2 = ops.default_depth(n, H, W, stride=2)
+            rec2, prec2 = scores(ops.depth_mask(cloud, tg, rg, (h2, w2), tau=t2, stride=2))
+            parity("furnished room, stride 2 on %dx%d tau %.3f: 1 - recall" % (w2, h2, t2), 1 - rec2, 0.10)
+            parity("furnished room, stride 2: 1 - precision", 1 - prec2, 0.25)
+            assert 0.15 < occ.mean() < 0.30
+            assert rec_fine < 0.5 * rec and prec_fine > 0.95, (rec_fine, prec_fine)         # the panorama's grid: precise and nearly blind
     plain, masked, hidden = stats["furnished"]
-    assert 0.03 < hidden < 0.25, stats
-    assert masked < 0.75 * plain, stats
-    assert stats["box"][2] < 0.5 * hidden and stats["box"][1] > 0.8 * stats["box"][0], stats
+    assert 0.15 < hidden < 0.35, stats
+    assert masked < 0.6 * plain, stats
+    assert stats["box"][2] < 0.25 * hidden and stats["box"][1] > 0.8 * stats["box"][0], stats
 
 
-def test_depth_mask_refresh_bound(ops):
-    """cfg depth_refresh_t / depth_refresh_r (build-defined, include/piccolo_hip.h): a candidate's depth mask is recomputed only
-    when its forward pose has left the bound around the pose the mask in use was computed for.  Bounds of 0 = the mask of the
-    current pose at every iteration (round 3's behaviour: the same bits); huge bounds = the starting pose's mask throughout (one
-    computation per candidate); a small bound recomputes while the pose still moves and stops as the steps shrink, and lands where
-    the every-iteration run lands."""
+def test_depth_mask_workspace_is_scratch_and_runs_compose(ops):
+    """nothing of the depth mask persists between pcl_gd_run calls — the z-buffers live in the caller's workspace and
+    are refilled by every iteration, the state holds optimiser records only.  So a run in pieces equals the run in one go, a state
+    may be continued with ANOTHER workspace (here: one full of garbage), and a state initialised without the mask may be run with
+    it."""
     from piccolo_amd import synth
-    n, H, W, B, tau = 40_000, 128, 256, 4, 0.02
-    xyz, rgb = synth.box_room(n, 17)
-    inner, inner_rgb = synth.box_room(n // 4, 18)
-    xyz = np.concatenate([xyz, inner * 0.25 + np.array([1.5, 1.0, 0.0], np.float32)]).astype(np.float32)
-    rgb = np.concatenate([rgb, inner_rgb]).astype(np.float32)
+    n, H, W, B = 40_000, 128, 256, 4
+    xyz, rgb = _occluder_scene(n)
     t_gt, ypr_gt = synth.gt_pose(17)
     trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=17, sigma_t=0.1, sigma_r=0.05)
     X, C = T(xyz), T(rgb)
@@ -786,38 +900,31 @@ def test_depth_mask_refresh_bound(ops):
     img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, T(t_gt), T(ypr_gt)), C, (H, W)))
     pano, box = ops.Pano(img), ops.quantile_box(X, 0.05)
 
-    def run(n_it, **kw):
-        gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True, depth_mask=True,
-                                 depth_tau=tau, **kw)
-        gd.run(n_it)
-        return gd.result().cpu().numpy(), gd.depth_refresh_counts().cpu().numpy()
-
-    every, c_every = run(60)
-    again, _ = run(60, depth_refresh_t=0.0, depth_refresh_r=0.0)
-    assert np.array_equal(every, again) and (c_every >= 55).all() and (c_every <= 60).all()     # (a pose that did not move keeps its mask)
-    once, c_once = run(60, depth_refresh_t=1e9, depth_refresh_r=1e9)
-    assert (c_once == 1).all() and not np.array_equal(once, every)
-    # Adam's steps are ~lr per parameter until the scheduler has cut lr: a bound that skips anything is a visible one
-    some, c_some = run(60, depth_refresh_t=2e-2, depth_refresh_r=2e-2)
-    assert (c_some < c_every).all() and (c_some >= 3).all(), (c_some, c_every)
-    # depth_every = 4 with bounds 0: every fourth iteration (15 masks in 60 iterations while the pose moves)
-    fourth, c_fourth = run(60, depth_every=4)
-    assert (c_fourth <= 15).all() and (c_fourth >= 13).all(), c_fourth
+    def make(**kw):
+        return ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True, depth_mask=True, **kw)
+    gd = make()
+    gd.run(60)
+    whole = gd.result().cpu().numpy()
+    gd = make()
+    gd.run(25)
+    gd.ws = torch.full_like(gd.ws, 0x5A)                      # continue with a different workspace
+    gd.run(35)
+    assert np.array_equal(gd.result().cpu().numpy(), whole)
+    gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True)     # state made without the mask
+    masked = make()
+    gd.hyper, gd.ws, gd.ws_bytes = masked.hyper, masked.ws, masked.ws_bytes
+    gd.run(60)
+    assert np.array_equal(gd.result().cpu().numpy(), whole)
+    plain = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
+    plain.run(60)
+    assert not np.array_equal(plain.result().cpu().numpy(), whole)
     R_gt = synth.rot_from_ypr_np(ypr_gt)
-    for res in (every, some, fourth):
-        k = int(np.argmin(res[:, 12]))
-        e = synth.pose_errors(res[k, :3], ops.rot_from_ypr(T(res[k:k + 1, 3:6]))[0].cpu().numpy(), t_gt, R_gt)
-        assert e[0] < 0.05 and e[1] < 1.0, e
-    assert np.abs(some[:, :3] - every[:, :3]).max() < 0.05
-    # run() in pieces keeps the records; reset() starts them afresh
-    gd = ops.GradientDescent(cloud, pano, T(trans), T(rot), box, lr=0.1, patience=5, factor=0.8, batch_mode=True, depth_mask=True,
-                             depth_tau=tau, depth_refresh_t=2e-2, depth_refresh_r=2e-2)
-    gd.run(25); gd.run(35)
-    assert np.array_equal(gd.result().cpu().numpy(), some) and np.array_equal(gd.depth_refresh_counts().cpu().numpy(), c_some)
-    gd.reset(T(trans), T(rot))
-    assert (gd.depth_refresh_counts().cpu().numpy() == 0).all()
-    with pytest.raises(Exception):
-        ops.GradientDescent(cloud, pano, T(trans), T(rot), box, depth_mask=True, depth_refresh_t=-1.0).run(1)
+    k = int(np.argmin(whole[:, 12]))
+    e = synth.pose_errors(whole[k, :3], ops.rot_from_ypr(T(whole[k:k + 1, 3:6]))[0].cpu().numpy(), t_gt, R_gt)
+    assert e[0] < 0.05 and e[1] < 1.0, e
+    for bad in (dict(depth_tau=-1.0), dict(depth_res=(0, 400)), dict(depth_res=(1 << 15, 1 << 16))):
+        with pytest.raises(Exception):
+            make(**bad).run(1)
 
 
 def test_gd_graph_replay_is_bit_identical(ops):

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Depth-mask pass alone (z pass + mark pass) for B candidate poses: time per call.   python tools/dbench.py [B]"""
+"""The depth passes alone for B candidate poses at cfg-2 size: pcl_depth_mask (pose setup + fill + z pass + mark) per call for a
+list of (grid, occluder stride) combinations; the mark pass is the same in all of them (every point is tested), so differences are
+the z pass's.   python tools/dbench.py [B]      (PCL_ZFORM / PCL_ZPTS / PCL_ZWIN: see csrc/pcl_depth.hip)"""
 import os
 import sys
 
@@ -16,13 +18,14 @@ cloud = ops.Cloud(torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev))
 t_gt, ypr_gt = synth.gt_pose(0)
 tr, ro = synth.start_poses(t_gt, ypr_gt, B, 0)
 TR, RO = torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev)
-vis = ops.depth_mask(cloud, TR, RO, (H, W))
-torch.cuda.synchronize()
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-a.record()
-for _ in range(10):
-    vis = ops.depth_mask(cloud, TR, RO, (H, W))
-b.record()
-torch.cuda.synchronize()
-print("variant %s B=%d: %.1f us per depth-mask call, visible fraction %.4f" % (os.environ.get("PCL_ZPASS_VARIANT", "-"), B, a.elapsed_time(b) * 100,
-                                                                               float(vis.float().mean())))
+for res, stride in (((200, 400), 1), ((200, 400), 2), ((200, 400), 4), ((200, 400), 64), ((144, 288), 1), ((144, 288), 2), ((96, 192), 4), ((H, W), 1)):
+    vis = ops.depth_mask(cloud, TR, RO, res, stride=stride)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        vis = ops.depth_mask(cloud, TR, RO, res, stride=stride)
+    b.record()
+    torch.cuda.synchronize()
+    print("grid %4dx%-4d stride %2d B=%d form=%s: %.1f us per depth-mask call (fill + z pass + mark), visible fraction %.4f"
+          % (res[1], res[0], stride, B, os.environ.get("PCL_ZFORM", "auto"), a.elapsed_time(b) * 100, float(vis.float().mean())))
