@@ -69,7 +69,12 @@ def self_launch(argv):
             s.bind(("127.0.0.1", 0))
             port = str(s.getsockname()[1])
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this host driver
+    # dmabuf IPC: on this pool's host driver RCCL between processes fails with `hipIpcGetMemHandle: invalid argument` under the
+    # legacy IPC mode.  A DEFAULT only: a value already in the environment (the driver's, or PCL_HSA_IPC_MODE_LEGACY to force one
+    # for an experiment) wins, and every rank prints the value it runs with.
+    if "PCL_HSA_IPC_MODE_LEGACY" in env:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = env["PCL_HSA_IPC_MODE_LEGACY"]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")                   # (torchrun would set it, with a warning; cpu_baseline sizes its own pool)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", port, "--", os.path.abspath(__file__)] + list(argv)
@@ -224,22 +229,49 @@ class Ranks:
         self.dev = torch.device("cuda", dev_index)
         self.dist = None
         if self.world > 1 or os.environ.get("PCL_BENCH_FORCE_DIST") == "1":   # (the env knob exercises the RCCL path at world size 1)
+            import datetime
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+            if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:             # (experiments: what happens without dmabuf IPC)
+                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)     # RCCL
-            else:
-                dist.init_process_group(self.backend)
+            # An explicit, SHORT rendezvous / collective timeout: a rank that cannot reach the others must end the job with a reason
+            # inside the driver's own time limit, not hang in it (torch's default is 10 minutes for nccl, 30 for gloo).
+            self.timeout_s = float(os.environ.get("PCL_DIST_TIMEOUT_S", "180"))
+            tmo = datetime.timedelta(seconds=self.timeout_s)
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.backend == "nccl" else "-"
+            except Exception as exc:                                # noqa: BLE001
+                rccl = "unknown (%s)" % exc
+            print("bench.py rank %d/%d: pid %d, device cuda:%d of %d visible (%s), backend %s, RCCL %s, HSA_ENABLE_IPC_MODE_LEGACY=%s, "
+                  "rendezvous %s:%s, timeout %.0f s" % (self.rank, self.world, os.getpid(), dev_index, self.n_dev, torch.cuda.get_device_name(dev_index),
+                                                        self.backend, rccl, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ["MASTER_ADDR"],
+                                                        os.environ["MASTER_PORT"], self.timeout_s), file=sys.stderr, flush=True)
+            try:
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev, timeout=tmo)     # RCCL
+                else:
+                    dist.init_process_group(self.backend, timeout=tmo)
+            except Exception as exc:                                # noqa: BLE001
+                self.fail("init_process_group(%s)" % self.backend, exc)
             self.dist = dist
         self.coll_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
 
+    def fail(self, what, exc):
+        """a collective failed: ONE line with the reason on stderr and a non-zero exit (no JSON line: the launcher / driver sees rc != 0)"""
+        print("bench.py rank %d/%d: %s FAILED: %s: %s" % (self.rank, self.world, what, type(exc).__name__, str(exc).replace("\n", " | ")[:600]),
+              file=sys.stderr, flush=True)
+        os._exit(3)                                                 # (not sys.exit: a hung communicator must not block the interpreter's teardown)
+
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            try:
+                self.dist.barrier()
+            except Exception as exc:                                # noqa: BLE001
+                self.fail("barrier", exc)
 
     def gather(self, rows):
         """the path's only collective: every rank's result rows (RCCL all_gather; gloo in the CPU tests)"""
@@ -247,15 +279,35 @@ class Ranks:
             return rows
         src = rows.contiguous() if self.backend == "nccl" else rows.cpu()
         out = torch.empty(self.world * src.shape[0], src.shape[1], device=src.device)
-        self.dist.all_gather_into_tensor(out, src)
+        try:
+            self.dist.all_gather_into_tensor(out, src)
+            if self.backend == "nccl":
+                torch.cuda.synchronize()                            # (an asynchronous RCCL error surfaces here, inside the try)
+        except Exception as exc:                                    # noqa: BLE001
+            self.fail("all_gather_into_tensor (%d x %d floats per rank)" % (src.shape[0], src.shape[1]), exc)
         return out
 
     def max_over_ranks(self, seconds):
         if self.dist is None:
             return seconds
         t = torch.tensor([seconds], device=self.coll_dev, dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        try:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        except Exception as exc:                                    # noqa: BLE001
+            self.fail("all_reduce(MAX)", exc)
         return float(t.item())
+
+    def all_ranks(self, value):
+        """[value of rank 0, ..., value of rank world - 1] on every rank (one float per rank: the per-rank step times)"""
+        if self.dist is None:
+            return [float(value)]
+        src = torch.tensor([float(value)], device=self.coll_dev, dtype=torch.float64)
+        out = torch.empty(self.world, device=self.coll_dev, dtype=torch.float64)
+        try:
+            self.dist.all_gather_into_tensor(out, src)
+        except Exception as exc:                                    # noqa: BLE001
+            self.fail("all_gather_into_tensor (per-rank times)", exc)
+        return [float(v) for v in out.cpu()]
 
     def agree(self, flag):
         """rank 0's decision, on every rank"""
@@ -364,6 +416,7 @@ class Measure:
         if with_gather:
             self.ranks.gather(results[:K])
         torch.cuda.synchronize()
+        self.last_local_s = time.perf_counter() - t0           # this rank's own K steps (+ gather), before it waits for the others
         self.ranks.barrier()
         torch.cuda.synchronize()
         return self.ranks.max_over_ranks(time.perf_counter() - t0)
@@ -371,15 +424,17 @@ class Measure:
     def repeated(self, items, results, K, tm, min_seconds, with_gather=True):
         """timed passes until `min_seconds` of measurement (the count is agreed between ranks: rank 0's clock decides);
         returns the list of pass times, the median pass and the kernel-timer reading of that pass"""
-        times, kernels, total = [], [], 0.0
+        times, kernels, locals_, total = [], [], [], 0.0
         while True:
             dt = self.timed_pass(items, results, K, tm, with_gather)
             times.append(dt)
+            locals_.append(self.last_local_s)
             kernels.append(tm.read() if tm is not None else (0.0, 0))
             total += dt
             if not self.ranks.agree(total < min_seconds and len(times) < 200):
                 break
         mid = int(np.argsort(times)[len(times) // 2])
+        self.local_s_of_median_pass = locals_[mid]             # (the pass times are identical on every rank: the same `mid` everywhere)
         return times, times[mid], kernels[mid]
 
 
@@ -684,6 +739,8 @@ def main():
     pass_times, elapsed, (kernel_ms, launches) = m.repeated(timed_items, results, K, timer, args.min_seconds)
     # proof that the collective really spanned N ranks: distinct rank stamps among the gathered rows
     ranks_seen = int(torch.unique(ranks.gather(results[:K])[:, 14]).numel())
+    # every rank's OWN time for the median pass's K steps (before it waited for the others): a straggler shows as max >> min
+    per_rank_s = ranks.all_ranks(m.local_s_of_median_pass)
 
     # accuracy of this rank's images (localize.py:239-247 formulas)
     errs = []
@@ -772,6 +829,10 @@ def main():
                        "poses_per_launch": ipl * B, "texels": fmt_name, "warmup_images": "distinct from the timed ones"},
             "passes": len(pass_times), "pass_ms": {"min": min(pass_times) * 1e3, "median": elapsed * 1e3, "max": max(pass_times) * 1e3},
             "ranks_seen": ranks_seen, "devices_visible": ranks.n_dev,
+            "per_rank_ms_per_step": {"min": min(per_rank_s) / K * 1e3, "max": max(per_rank_s) / K * 1e3, "ranks": [v / K * 1e3 for v in per_rank_s],
+                                     "is": "each rank's own wall time for the median pass's K steps (+ its side of the gather), before "
+                                           "the closing barrier; ms_per_step is the barrier-to-barrier time, MAX over ranks"},
+            "dist_backend": ranks.backend if ranks.dist is not None else None,
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
             "single_image": single,
@@ -787,7 +848,7 @@ def main():
         pass
     sys.stdout.flush()
     if ranks.dist is not None:
-        ranks.dist.barrier()
+        ranks.barrier()
         ranks.dist.destroy_process_group()
         ranks.dist = None
     if rank != 0:

@@ -8,7 +8,9 @@
 //
 // Order: ascending by value, ties by ascending index (a stable argsort); `largest`: descending by value, ties by DESCENDING index
 // (= the last n of the stable ascending order, flipped: what utils.py:583-584 does with a stable sort).  NaN ranks last in both
-// modes (the reference's scores hold no NaN, utils.py:579; a NaN loss — a pose that samples nothing — is never preferred).
+// modes (the reference's scores hold no NaN, utils.py:579; a NaN loss — a pose that samples nothing — is never preferred); -0.0 and
+// +0.0 are one value.  The torch.topk fallbacks for n_keep > 1024 (piccolo_amd/utils.py) are fed NaN-free copies (NaN -> +-inf on
+// the losing side), so both paths share this order.
 #include <stdint.h>
 
 #include "pcl_device.h"
@@ -19,6 +21,7 @@
 __device__ __forceinline__ unsigned long long pcl_sel_composite(float v, unsigned idx, int largest)
 {
     unsigned u = __float_as_uint(v);
+    if (v == 0.f) u = 0u;                                               // -0.0 == +0.0: one key, the tie goes to the index (as argsort / topk)
     unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // order-preserving: ascending floats -> ascending keys
     if (largest) key = ~key;
     if (v != v) key = 0xffffffffu;                                      // NaN: last

@@ -116,9 +116,11 @@ def packed_pano(img, many_poses=False, n_points=None):
     """Packed panorama of `img`, cached per tensor.  RGBA8 texels (half the footprint of the fp16-level default) when the launch
     evaluates hundreds of candidate poses all over the room (`many_poses`, trim_input_loss: with 1800 poses the fp16 texture
     thrashes L2, 8.7 vs 5.3 ms per launch at cfg-2 size) or when the cloud to be refined is sparse against the panorama
-    (`n_points`: ops.refine_texels — the refinement then shares the trim stage's packing of the image); fp16-level texels
-    otherwise (the refinement's nearby poses on a dense cloud run 5 % faster on them).  Images that are not k/255 get float4
-    texels either way."""
+    (`n_points`: ops.refine_texels); fp16-level texels otherwise (the refinement's nearby poses on a dense cloud run 5 % faster on
+    them).  The trim launch of a SPARSE cloud takes its own layout ('u8p', rows interleaved in pairs, cache 'pano_u8p'), so at the
+    shipped 167k-point shape an image whose initialisation and refinement use the same tensor is packed twice (8 MB each, two
+    caches): the two stages share a packing only for dense clouds' trim ('u8') and a sparse cloud's refinement ('u8').  Images that
+    are not k/255 get float4 texels either way."""
     rgba8 = many_poses or (n_points is not None and ops.refine_texels(n_points, img.shape[0], img.shape[1]) == "u8")
     if os.environ.get("PCL_PANO_FMT") in ("f16", "f32") and not many_poses:      # experiments: force the refinement's format
         rgba8 = False

@@ -381,21 +381,33 @@ def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
     nproj = torch.empty(I * K, nblk, dtype=torch.int32, device=dev)
     nimg = torch.empty(I, nblk, dtype=torch.int32, device=dev)
     scores = torch.empty(I, K, dtype=F32, device=dev)
-    per_image = max(lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w), 1)
-    if lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w) == 0:
+    per_image = lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w)
+    if per_image == 0:
         raise ValueError("hist_trim_scores_images: need num_split_h >= 3 and blocks of at least one pixel")
     group = max(1, min(HIST_MAX_IMAGES, I, int(8e9 // per_image)))
     t2, r2 = trans.reshape(I * K, 3).contiguous(), rot.reshape(I * K, 3).contiguous()
-    for i0 in range(0, I, group):
+    i0 = 0
+    while i0 < I:
         m = min(group, I - i0)
         nws = lib.pcl_hist_trim_images_workspace_bytes(cloud.n, m, K, H, W, num_split_h, num_split_w)
-        ws = _bytes(nws)
+        try:
+            ws = _bytes(nws)
+        except torch.cuda.OutOfMemoryError:
+            # like hist_trim_scores: fewer images at a time, and in the end the per-image path with its own fallbacks
+            torch.cuda.empty_cache()
+            if group > 1:
+                group = (group + 1) // 2
+                continue
+            scores[i0] = hist_trim_scores(imgs[i0], cloud, trans[i0], rot[i0], num_split_h, num_split_w)
+            i0 += 1
+            continue
         arr = (ctypes.c_void_p * m)(*[im.data_ptr() for im in imgs[i0:i0 + m]])
         _lib.check(lib.pcl_hist_trim_scores_images(_ptr(cloud.data), cloud.n, arr, m, K, H, W, _ptr(t2[i0 * K:]), _ptr(r2[i0 * K:]), num_split_h,
                                                    num_split_w, _ptr(inter[i0 * K:]), _ptr(nproj[i0 * K:]), _ptr(nimg[i0:]), _ptr(ws), nws, _stream()),
                    "pcl_hist_trim_scores_images")
         _lib.check(lib.pcl_hist_trim_reduce_images(_ptr(inter[i0 * K:]), _ptr(nproj[i0 * K:]), _ptr(nimg[i0:]), m, K, num_split_h, num_split_w,
                                                    _ptr(scores[i0:]), _stream()), "pcl_hist_trim_reduce_images")
+        i0 += m
     return scores
 
 

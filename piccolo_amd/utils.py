@@ -194,7 +194,8 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     if num_input <= ops.SELECT_MAX_KEEP:
         tt, tr = ops.select_poses(table, num_input, trans, rot, largest=False, rot_per_trans=Rn)
         return _like(tt, trans), _like(tr, rot)
-    min_inds = torch.topk(table, num_input, largest=False, sorted=True).indices.to(trans.device)
+    # (more than SELECT_MAX_KEEP survivors: torch.topk, with NaN made to lose as in pcl_select_poses — topk itself ranks NaN first)
+    min_inds = torch.topk(torch.nan_to_num(table, nan=float("inf")), num_input, largest=False, sorted=True).indices.to(trans.device)
     return trans[torch.div(min_inds, Rn, rounding_mode="floor")], rot[min_inds % Rn]
 
 
@@ -207,7 +208,7 @@ def trim_input_hist_secondary(img, xyz, rgb, trans, rot, num_input, num_split_h,
     if n <= ops.SELECT_MAX_KEEP:                    # flip(argsort()[-n:]) and the two gathers (utils.py:583-586) in one launch
         tt, tr = ops.select_poses(scores, n, trans, rot, largest=True)
         return _like(tt, trans), _like(tr, rot)
-    order = torch.topk(scores, n, largest=True, sorted=True).indices.to(trans.device)   # best first
+    order = torch.topk(torch.nan_to_num(scores, nan=float("-inf")), n, largest=True, sorted=True).indices.to(trans.device)   # best first, NaN last
     return trans[order], rot[order]
 
 

@@ -314,7 +314,7 @@ def test_select_poses_is_the_reference_argsort_and_decode():
         v[rng.integers(0, M, M // 10)] = np.float32(0.25)              # ties
         v[rng.integers(0, M, max(1, M // 50))] = np.nan
         if M > 4:
-            v[1], v[3] = np.float32(-0.0), np.float32(0.0)
+            v[1], v[3] = np.float32(0.0), np.float32(-0.0)             # one value: the tie goes to the index (-0.0 must not rank first)
         n = min(n, M)
         trans, rot = rng.normal(size=(K, 3)).astype(np.float32), rng.normal(size=(R, 3)).astype(np.float32)
         tt, tr, idx = ops.select_poses(torch.from_numpy(v).to(dev), n, torch.from_numpy(trans).to(dev), torch.from_numpy(rot).to(dev),
