@@ -164,6 +164,16 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
         // costs 30 VGPRs; the kernel is VALU-issue bound, not latency bound.)
 #ifndef PCL_NO_ROTATE_PAIR
         f2 rot_p[G][3];
+#ifdef PCL_TIMING_ONLY_NO_ROTATION
+        // TIMING ONLY (profiles/r05/experiments/mfma_rotation_bound.txt): what the kernel would take if q = x - t, p = R q cost the
+        // VALUs nothing — the upper bound of moving the rotation to the matrix pipe.  The poses still differ (a per-pose offset from one
+        // scalar, two packed adds), so nothing downstream folds away; the RESULTS ARE WRONG.
+        if constexpr (G == 2) {
+            const f2 oa = F2((a.poses + pose0)->t[0]), ob = F2((a.poses + pose0 + 1)->t[0]);
+            rot_p[0][0] = x - oa; rot_p[0][1] = y; rot_p[0][2] = z;
+            rot_p[1][0] = x - ob; rot_p[1][1] = y; rot_p[1][2] = z;
+        } else
+#endif
         if constexpr (G == 2) {
             if constexpr (FUSED) pcl_rotate2x2(x, y, z, P6[0], P6[1], rot_p[0][0], rot_p[0][1], rot_p[0][2], rot_p[1][0], rot_p[1][1], rot_p[1][2]);
             else pcl_rotate2x2(x, y, z, pcl_pose6(a.poses + pose0), pcl_pose6(a.poses + pose0 + 1), rot_p[0][0], rot_p[0][1], rot_p[0][2],
