@@ -188,6 +188,26 @@ def cpu_baseline(xyz, rgb, img, trans, rot, budget_s=12.0):
             "pose_evals_per_s": pose_evals_per_s}
 
 
+def pipeline_kernel_roofs(tag):
+    """The binding roof of every kernel of a pipeline shape — trim: L1 line lookups per cycle per CU, bin / resolve / z pass: whichever
+    of VALU issue, LDS, memory-side atomics or bytes explains them — from the rocprofv3 counter passes of that pipeline
+    (profiles/pipeline_roofs.json, written by profiles/summarize.py: PIPELINE_TAG).  Stamped with pcl_library_hash() of the library
+    they were collected from; another build's numbers are not reported."""
+    path = os.path.join(REPO, "profiles", "pipeline_roofs.json")
+    try:
+        entry = json.load(open(path)).get(tag)
+    except Exception as exc:                                    # noqa: BLE001
+        return {"unavailable": "cannot read %s: %s" % (path, exc)}
+    if not entry:
+        return {"unavailable": "no entry %r in profiles/pipeline_roofs.json" % tag}
+    loaded = _lib.load().pcl_library_hash().decode()
+    if entry.get("library_hash") != loaded:
+        return {"unavailable": "stale: profiled library %s, loaded library %s" % (entry.get("library_hash"), loaded)}
+    return {"source": entry.get("source"), "command": entry.get("command"), "library_hash": loaded,
+            "kernels": {k: {"us": v.get("avg_duration_us_kernel_trace"), "binding_roof": v.get("binding_roof"), "frac": v.get("binding_frac"),
+                            "all": v.get("roof_fractions")} for k, v in sorted(entry.get("kernels", {}).items())}}
+
+
 def lookup_roofs(path, workload, poses_per_launch, fmt_name, lib_hash):
     """Counter-derived figures for exactly this launch shape (profiles/roofs.json, written by profiles/summarize.py from
     the rocprofv3 --pmc passes).  -> (key, entry or None, why-not or None).  An entry collected from a library whose loss
@@ -872,11 +892,15 @@ def main():
             also["shipped_8_images_per_chain"] = run_side("shipped", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=8, ipl=8)
             if (1_000_000, 1024, 2048) in scenes and world == 1:
                 also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
+                also["pipeline"]["kernel_roofs"] = pipeline_kernel_roofs("pipeline_cfg2")
             if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
                 also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
+                also["pipeline_shipped"]["kernel_roofs"] = pipeline_kernel_roofs("pipeline_shipped")
                 also["pipeline_shipped_8_images"] = pipeline_images_block(scenes[(166_667, 1024, 2048)], ipl=8)
             if (1_000_000, 1024, 2048) in scenes and world == 1:
                 also["depth_mask_cfg2"] = depth_mask_block(scenes[(1_000_000, 1024, 2048)], 32)
+                also["depth_mask_cfg2"]["kernel_roofs"] = {"default_grid": pipeline_kernel_roofs("depth_mask_cfg2"),
+                                                           "every_point": pipeline_kernel_roofs("depth_mask_cfg2_every_point")}
                 also["depth_mask_cfg3"] = depth_mask_block(scenes[(1_000_000, 1024, 2048)], 256, n_images=1, panorama_grid=False)
             if args.workload != "cfg5" and world == 1:
                 also["cfg5"] = run_side("cfg5", ranks, args, lib_hash, pair_ms, args.timer_stride, scenes, K=2, ipl=2)

@@ -43,6 +43,9 @@ const char *pcl_error_string(int code);
  * Measurement aid: counter-derived figures (VALU instructions per point-pose, profiles/roofs.json) carry the hash of the
  * library they were collected from, and bench.py reports them only for a library with the same hash. */
 const char *pcl_source_hash(void);
+/* The same over EVERY source of the library (csrc/*.hip, csrc/*.h, this header): what the per-kernel roofs of the pipeline kernels
+ * (trim, bin / resolve, z pass: profiles/pipeline_roofs.json) are stamped with. */
+const char *pcl_library_hash(void);
 
 /* ---- data layout in HBM ------------------------------------------------------------------------------------
  * cloud : 6 planes (x, y, z, -r, -g, -b) of pcl_cloud_stride(n) floats each (colours negated: the loss needs c - rgb) — SoA so that a wavefront's 64 lanes
@@ -257,7 +260,8 @@ size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw);
 /* Same for a cloud of n points, large enough for the tile-binned render (ABI v4): every candidate's points are binned by the
  * 64 x 64-pixel image tile(s) their 3 x 3 splat touches and every tile is resolved and histogrammed in LDS — no z-buffer in
  * HBM, bit-identical scores.  pcl_hist_trim_scores takes that path when its workspace is at least this large (4 n list
- * entries of 12 bytes per candidate: the exact worst case) and the z-buffer splat otherwise. */
+ * entries of 12 bytes per candidate: the exact worst case; plus 8 n bytes for the projections the count pass hands to the scatter pass)
+ * and the z-buffer splat otherwise. */
 size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw);
 int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, int H, int W, const float *trans,
                          const float *rot, int ncand, int nsh, int nsw, float *inter, int32_t *nproj, int32_t *nimg,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "pcl_abi_version": (_int, []),
     "pcl_error_string": (_c.c_char_p, [_int]),
     "pcl_source_hash": (_c.c_char_p, []),
+    "pcl_library_hash": (_c.c_char_p, []),
     "pcl_cloud_stride": (_i64, [_i64]),
     "pcl_cloud_bytes": (_sz, [_i64]),
     "pcl_cloud_pack": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

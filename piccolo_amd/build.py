@@ -37,6 +37,17 @@ def loss_kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def library_source_hash():
+    """First 16 hex digits of sha256 over EVERY source of the library (csrc/*.hip, csrc/*.h, include/piccolo_hip.h, sorted by name): what
+    pcl_library_hash() returns.  The per-kernel roofs of the pipeline kernels (profiles/pipeline_roofs.json) carry it."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "piccolo_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def stale():
     if not os.path.exists(SO):
         return True
@@ -51,7 +62,8 @@ def build(force=False, verbose=False, extra_flags=()):
         return SO
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-pthread",
-           "-Wall", "-Wno-unused-function", '-DPCL_SOURCE_HASH="%s"' % loss_kernel_source_hash(), "-o", SO] + list(extra_flags) + sources()
+           "-Wall", "-Wno-unused-function", '-DPCL_SOURCE_HASH="%s"' % loss_kernel_source_hash(), '-DPCL_LIBRARY_HASH="%s"' % library_source_hash(),
+           "-o", SO] + list(extra_flags) + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -138,6 +138,9 @@ struct PclBinArgs {
     int* order;                        // [ncand][nt]      tiles by decreasing count: the resolve kernel's launch order
     uint32_t* lists;                   // [ncand][3][cap]  per entry: pixel (row << 16 | col), depth bits, packed point slot
     int64_t cap;                       // entries per candidate (4 n: a 3 x 3 splat touches at most four tiles)
+    uint32_t* pcache;                  // [ncand][2][n]    round 5: every point's (pixel after the pre-dedup, depth bits), written by the
+                                       // count pass and read back by the scatter pass, which used to project every point a second time
+                                       // (two library atan2f per point: the pixels must match make_pano's bit for bit)
 };
 
 // pixel of packed point i for pose pr, exactly as pcl_splat_poses_kernel computes it
@@ -205,20 +208,26 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
     uint32_t pix[PER], dep[PER];
+    uint32_t* __restrict__ pc = a.pcache + (int64_t)cand * 2 * a.n;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int64_t i = first + (int64_t)k * PCL_BLOCK;
         pix[k] = 0xffffffffu;                          // (row 65535 does not exist: H < 65536)
         dep[k] = 0u;
         if (i < a.n) {
-            int row, col;
-            float d;
-            pcl_bin_project(a, a.poses + cand, i, row, col, d);
-            pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
-            dep[k] = __float_as_uint(d);
+            if (SCATTER) {                             // the count pass's projection AND its dedup decision, read back
+                pix[k] = pc[i];
+                dep[k] = pc[a.n + i];
+            } else {
+                int row, col;
+                float d;
+                pcl_bin_project(a, a.poses + cand, i, row, col, d);
+                pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
+                dep[k] = __float_as_uint(d);
+            }
         }
     }
-    if (DEDUP) {
+    if (DEDUP && !SCATTER) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             // (`|`, not `||`: every lane takes part in every DPP read — a short-circuit would switch source lanes off)
@@ -227,6 +236,13 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
             if (PCL_BIN_NEIGH >= 4) dom |= (int)pcl_bin_dominated_by<4>(pix[k], dep[k]);
             if (dom) pix[k] = 0xffffffffu;             // a nearer point owns this pixel (the compares above all saw the originals:
         }                                              // k is a different point set per trip)
+    }
+    if (!SCATTER) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int64_t i = first + (int64_t)k * PCL_BLOCK;
+            if (i < a.n) { pc[i] = pix[k]; pc[a.n + i] = dep[k]; }
+        }
     }
     int tiles[PER][4];
 #pragma unroll
@@ -587,7 +603,7 @@ static size_t hist_render_bytes(int64_t n, int H, int W)
     if (n <= 0) return zb;
     const size_t nt = (size_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
     if (!hist_binned_ok(n, H, W)) return zb;       // the launch would take the splat path anyway: no lists to hold
-    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12;
+    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12 + (size_t)n * 8;      // bookkeeping + lists + the projection cache
     return binned > zb ? binned : zb;
 }
 
@@ -671,6 +687,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.order = b.cursors + (int64_t)ncand * nt;
         b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
         b.cap = cap;
+        b.pcache = b.lists + (int64_t)ncand * 3 * cap;
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
         // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)

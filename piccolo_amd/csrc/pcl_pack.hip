@@ -11,6 +11,10 @@ extern "C" int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 #define PCL_SOURCE_HASH "unstamped"
 #endif
 extern "C" const char* pcl_source_hash(void) { return PCL_SOURCE_HASH; }
+#ifndef PCL_LIBRARY_HASH
+#define PCL_LIBRARY_HASH "unstamped"
+#endif
+extern "C" const char* pcl_library_hash(void) { return PCL_LIBRARY_HASH; }
 
 extern "C" const char* pcl_error_string(int code)
 {

@@ -14,9 +14,12 @@ ROOF_KEY=shipped/poses6/u8 POINT_POSES=1000002 ROOF_SOURCE=$R/h_shipped_1image R
   bash profiles/collect.sh ${R}_h --workload shipped --images-per-launch 1 $PMC
 ROOF_KEY=shipped/poses48/u8 POINT_POSES=8000016 ROOF_SOURCE=$R/i_shipped_8images ROOF_CMD="bench.py --workload shipped --images-per-launch 8" \
   bash profiles/collect.sh ${R}_i --workload shipped --images-per-launch 8 $PMC
-bash profiles/collect.sh ${R}_e --script tools/init_bench.py
+PIPELINE_TAG=pipeline_cfg2 ROOF_SOURCE=$R/e_init_stage ROOF_CMD="tools/init_bench.py" bash profiles/collect.sh ${R}_e --script tools/init_bench.py
 bash profiles/collect.sh ${R}_f --script tools/chain_bench.py 167000 6 1
+PIPELINE_TAG=pipeline_shipped ROOF_SOURCE=$R/p_pipeline_shipped ROOF_CMD="tools/pipeline_trace.py 8" bash profiles/collect.sh ${R}_p --script tools/pipeline_trace.py 8
+PIPELINE_TAG=depth_mask_cfg2 ROOF_SOURCE=$R/z_depth_mask_cfg2 ROOF_CMD="tools/dgd_profile.py 32 20" bash profiles/collect.sh ${R}_z --script tools/dgd_profile.py 32 20
+PIPELINE_TAG=depth_mask_cfg2_every_point ROOF_SOURCE=$R/z1_depth_mask_cfg2_stride1 ROOF_CMD="tools/dgd_profile.py 32 20 1" bash profiles/collect.sh ${R}_z1 --script tools/dgd_profile.py 32 20 1
 # the driver's own command line (--steps 20 --warmup 5): 4 launch groups of 5 images = 160 poses per launch
 ROOF_KEY=cfg2/poses160/f16 POINT_POSES=160e6 ROOF_SOURCE=$R/g_driver_cfg2_5images ROOF_CMD="bench.py --steps 20 --warmup 5" \
   bash profiles/collect.sh ${R}_g --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline
-python3 profiles/merge_roofs.py gpurun_out/prof_${R}_*/summary/roofs.json
+python3 profiles/merge_roofs.py gpurun_out/prof_${R}_*/summary/roofs.json gpurun_out/prof_${R}_*/summary/pipeline_roofs.json

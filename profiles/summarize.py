@@ -18,14 +18,14 @@ import sys
 from collections import defaultdict
 
 
-def library_hash():
-    """pcl_source_hash() of the library the profiled command loaded (host-only call): bench.py scores an entry only for a library
-    with the same loss-kernel sources."""
+def library_hash(fn="pcl_source_hash"):
+    """pcl_source_hash() (loss-kernel sources) or pcl_library_hash() (every source) of the library the profiled command loaded
+    (host-only calls): bench.py scores an entry only for a library with the same sources."""
     import ctypes
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "piccolo_amd", "lib", "libpiccolo_hip.so")
     lib = ctypes.CDLL(os.environ.get("PCL_SO", so))
-    lib.pcl_source_hash.restype = ctypes.c_char_p
-    return lib.pcl_source_hash().decode()
+    getattr(lib, fn).restype = ctypes.c_char_p
+    return getattr(lib, fn)().decode()
 
 
 def short(name):
@@ -37,8 +37,11 @@ def main(d):
     os.makedirs(out, exist_ok=True)
     stats = glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True)
     lines = []
+    avg_ns = {}                                            # kernel -> average duration (ns) in the kernel-trace run
     for f in stats:
         rows = list(csv.DictReader(open(f)))
+        for r in rows:
+            avg_ns[short(r["Name"])] = float(r["AverageNs"])
         lines.append("# %s" % os.path.relpath(f, d))
         lines.append("%-72s %8s %14s %12s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
         for r in rows:
@@ -80,6 +83,39 @@ def main(d):
             for n in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"):
                 if n in m:
                     r[n.lower() + "_per_wave_cycle"] = m[n] / m["SQ_WAVE_CYCLES"]
+        # ---- the roof that BINDS this kernel (round 5): every candidate roof as achieved / peak, the largest one named.
+        # cycles of the dispatch = SQ_BUSY_CYCLES / 32 (the counter sums the 32 shader engines: calibrated on the loss kernel, whose
+        # VALU-busy fraction is known from three other routes); SQ_ACTIVE_INST_* count quad-cycles per wave.  Both sit in the SAME
+        # counter pass, so a short dispatch gives no ratio above 1 (GRBM_GUI_ACTIVE did: round 4's clamp is gone).
+        fr = {}
+        if "SQ_BUSY_CYCLES" in m and m["SQ_BUSY_CYCLES"] > 0:
+            cycles = m["SQ_BUSY_CYCLES"] / 32.0
+            r["dispatch_cycles"] = cycles
+            if "SQ_ACTIVE_INST_VALU" in m:
+                fr["valu_issue"] = 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles)            # 1024 SIMDs
+                r["valu_busy_frac"] = fr["valu_issue"]
+                r.pop("valu_busy_frac_raw", None); r.pop("valu_busy_note", None)
+            if "TCP_TOTAL_CACHE_ACCESSES_sum" in m:
+                fr["l1_line_lookups"] = m["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * cycles)      # one tag lookup per cycle per CU
+            if "SQ_LDS_IDX_ACTIVE" in m:
+                fr["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (256.0 * cycles)
+        dur = avg_ns.get(k)
+        if dur:
+            r["avg_duration_us_kernel_trace"] = dur / 1e3
+            if "hbm_bytes_per_launch" in r:
+                fr["hbm"] = r["hbm_bytes_per_launch"] / (dur * 1e-9) / 8.0e12
+            if "TCC_EA0_ATOMIC_sum" in m:
+                r["memory_side_atomic_requests"] = m["TCC_EA0_ATOMIC_sum"]
+                fr["memory_side_atomics"] = m["TCC_EA0_ATOMIC_sum"] * 64.0 / (dur * 1e-9) / 1.3e12   # 64-byte requests against 1.3 TB/s
+        if "TA_BUSY_avr" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
+            r["ta_busy_frac"] = m["TA_BUSY_avr"] / m["GRBM_GUI_ACTIVE"] if m["TA_BUSY_avr"] > 1.5 else m["TA_BUSY_avr"]
+        if fr:
+            r["roof_fractions"] = fr
+            r["binding_roof"] = max(fr, key=fr.get)
+            r["binding_frac"] = fr[r["binding_roof"]]
+            r["roofs_are"] = ("valu_issue: 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles); l1_line_lookups: TCP_TOTAL_CACHE_ACCESSES / (256 CUs x "
+                              "cycles), the texture path's tag-lookup rate; lds_busy: SQ_LDS_IDX_ACTIVE / (256 x cycles); hbm: memory-side bytes / "
+                              "duration / 8 TB/s; memory_side_atomics: TCC_EA0_ATOMIC x 64 B / duration / 1.3 TB/s (MI355X_MICROARCH.md)")
         if "SQ_INSTS_VALU" in m:
             r["valu_insts_per_launch"] = m["SQ_INSTS_VALU"]
             if point_poses and ((k.startswith("pcl_loss_kernel") and "true" in k.split("<")[1].split(",")[1]) or k.startswith("pcl_loss_fused_kernel")):
@@ -87,6 +123,15 @@ def main(d):
         roofs[k] = r
         print(k, {n: (round(v, 4) if isinstance(v, float) else v) for n, v in r.items() if n not in ("traffic_note", "kernel")})
     json.dump(roofs, open(os.path.join(out, "kernel_roofs.json"), "w"), indent=1, sort_keys=True)
+    ptag = os.environ.get("PIPELINE_TAG", "")
+    if ptag:
+        # profiles/pipeline_roofs.json format (bench.py attaches it to also.pipeline*): per pipeline shape, per kernel, the binding roof
+        keep = {k: {n: v for n, v in r.items() if n in ("avg_duration_us_kernel_trace", "binding_roof", "binding_frac", "roof_fractions", "hbm_bytes_per_launch",
+                                                         "l2_hit_frac", "memory_side_atomic_requests", "valu_insts_per_launch", "dispatches_sampled")}
+                for k, r in roofs.items() if "binding_roof" in r and r.get("avg_duration_us_kernel_trace", 0) >= float(os.environ.get("PIPELINE_MIN_US", "8"))}
+        json.dump({ptag: {"library_hash": library_hash(fn="pcl_library_hash"), "source": "profiles/%s" % os.environ.get("ROOF_SOURCE", os.path.basename(d.rstrip("/"))),
+                          "command": os.environ.get("ROOF_CMD", ""), "kernels": keep}},
+                  open(os.path.join(out, "pipeline_roofs.json"), "w"), indent=1, sort_keys=True)
     if key:
         # the GRAD variant of the loss kernel is the one bench.py's roofline is about
         # (a fused chain runs 1 plain + 99 fused launches per refinement: the entry is the kernel with the most dispatches)
