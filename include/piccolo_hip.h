@@ -43,7 +43,7 @@ const char *pcl_error_string(int code);
  * Measurement aid: counter-derived figures (VALU instructions per point-pose, profiles/roofs.json) carry the hash of the
  * library they were collected from, and bench.py reports them only for a library with the same hash. */
 const char *pcl_source_hash(void);
-/* The same over EVERY source of the library (csrc/*.hip, csrc/*.h, this header): what the per-kernel roofs of the pipeline kernels
+/* The same over EVERY source of the library (all .hip and .h files of csrc, this header): what the per-kernel roofs of the pipeline kernels
  * (trim, bin / resolve, z pass: profiles/pipeline_roofs.json) are stamped with. */
 const char *pcl_library_hash(void);
 

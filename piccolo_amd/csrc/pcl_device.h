@@ -144,8 +144,12 @@ __device__ inline void pcl_write_pose_rec_fast(PclPoseRec* rec, const float p[6]
 // Equirectangular projection of a camera-frame point (reference utils.py:44-59):
 //   theta = atan2(|p_xy|, p_z + 1e-6), phi = atan2(p_y, p_x + 1e-6) + pi, g = (1 - phi/pi, 2 theta/pi - 1)
 // written with the same operation order as the reference so the stand-alone op matches it to an ulp or two.
+// (fp contraction off: every call site — the stand-alone op, make_pano, the histogram stage's splat, bin and fix-up kernels — must
+//  produce the same bits for the same point; left to the optimiser, px * px + py * py became an fma at some sites and not at others,
+//  and one point in 64M landed in a neighbouring pixel: found when round 5's fix-up path was compared with the splat path)
 __device__ inline void pcl_cloud2idx_point(float px, float py, float pz, float& gx, float& gy)
 {
+#pragma clang fp contract(off)
     const float pi = 3.14159265358979323846f, two_pi = 6.28318530717958647692f;
     float rho = sqrtf(px * px + py * py);
     float theta = atan2f(rho, pz + 1e-6f);

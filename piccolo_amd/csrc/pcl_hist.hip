@@ -20,8 +20,16 @@
 
 #define PCL_HBINS 512   // 8 x 8 x 8
 
+// ||p|| with ONE rounding sequence at every call site (splat, bin, fix-up): the depth decides which point owns a pixel
+__device__ __forceinline__ float pcl_point_depth(float px, float py, float pz)
+{
+#pragma clang fp contract(off)
+    return sqrtf(px * px + py * py + pz * pz);
+}
+
 __device__ inline void pcl_pano_pixel_ref(float px, float py, float pz, int H, int W, int& row, int& col)
 {
+#pragma clang fp contract(off)
     // make_pano's pixel (utils.py:158-165) with the reference's operation order (same as pcl_ops.hip)
     float gx, gy;
     pcl_cloud2idx_point(px, py, pz, gx, gy);
@@ -66,7 +74,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_splat_poses_kernel(const float*
             float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
             float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
             pcl_pano_pixel_ref(px, py, pz, H, W, row[k], col[k]);
-            float d = sqrtf(px * px + py * py + pz * pz);
+            float d = pcl_point_depth(px, py, pz);
             base[k] = ((unsigned long long)__float_as_uint(d) << 29) | (unsigned long long)(0x1fffffffu - (uint32_t)i);
             rsum += row[k]; csum += col[k]; cnt += 1;
         }
@@ -138,6 +146,7 @@ struct PclBinArgs {
     int* order;                        // [ncand][nt]      tiles by decreasing count: the resolve kernel's launch order
     uint32_t* lists;                   // [ncand][3][cap]  per entry: pixel (row << 16 | col), depth bits, packed point slot
     int64_t cap;                       // entries per candidate (4 n: a 3 x 3 splat touches at most four tiles)
+    float fast_margin_x, fast_margin_y; // count pass: a fast-formula pixel coordinate farther than this from an integer is certain (0: reference formula for all)
     uint32_t* pcache;                  // [ncand][2][n]    round 5: every point's (pixel after the pre-dedup, depth bits), written by the
                                        // count pass and read back by the scatter pass, which used to project every point a second time
                                        // (two library atan2f per point: the pixels must match make_pano's bit for bit)
@@ -151,7 +160,30 @@ __device__ __forceinline__ void pcl_bin_project(const PclBinArgs& a, const PclPo
     float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
     float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
     pcl_pano_pixel_ref(px, py, pz, a.H, a.W, row, col);
-    d = sqrtf(px * px + py * py + pz * pz);
+    d = pcl_point_depth(px, py, pz);
+}
+
+// The same pixel from the loss kernel's fast atan2 (octant reduction + degree-8 polynomial, v_rcp / v_rsq: ~45 instructions against
+// ~170 for the two library atan2f of pcl_pano_pixel_ref), with a CERTIFICATE: the pixel coordinates come out within a few fp32 ulps
+// of the reference formula's (angle error <= 6e-7 rad against the library's, the affine chain's roundings: <= 1e-6 W pixels in all),
+// so whenever both coordinates are farther than `margin` from an integer — and inside the image — truncation gives the reference's
+// pixel.  Returns false otherwise (0.5-1.5 % of the points): those are recomputed with the reference formula (pcl_bin_kernel's fix-up
+// queue).  The bit-identity of the whole stage against the z-buffer splat path, which only knows the reference formula, is what
+// tests/test_hip_harness.py::test_hist_trim_tile_binned_equals_the_zbuffer_path checks on every scene it runs.
+__device__ __forceinline__ bool pcl_pano_pixel_fast(float px, float py, float pz, int H, int W, float margin_x, float margin_y, int& row, int& col)
+{
+    const float pi = 3.14159265358979323846f, inv_two_pi = 0.15915494309189532f, inv_pi = 0.31830988618379067154f;
+    const float rho2 = fmaf(px, px, py * py);
+    const float rho = rho2 * __builtin_amdgcn_rsqf(rho2 + 1e-37f);
+    const float theta = pcl_atan2_ypos(rho, pz + 1e-6f);
+    const float phi = pcl_atan2(py, px + 1e-6f) + pi;
+    const float gx = 2.0f * (1.0f - phi * inv_two_pi) - 1.0f, gy = 2.0f * (theta * inv_pi) - 1.0f;
+    const float cx = (gx + 1.0f) * 0.5f * (float)(W - 1), cy = (gy + 1.0f) * 0.5f * (float)(H - 1);
+    const float fx = cx - floorf(cx), fy = cy - floorf(cy);
+    col = (int)cx; row = (int)cy;
+    // (a NaN coordinate fails every compare: not certain)
+    return fx > margin_x && fx < 1.0f - margin_x && fy > margin_y && fy < 1.0f - margin_y && cx > margin_x && cx < (float)(W - 1) - margin_x &&
+           cy > margin_y && cy < (float)(H - 1) - margin_y;
 }
 
 // the (up to four) tiles a 3 x 3 splat centred on (row, col) touches, after the clamp to the image
@@ -203,29 +235,67 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     extern __shared__ int lds[];                       // cnt[nt] (+ base[nt] when scattering)
     int* cnt = lds;
     int* base = lds + a.nt;
+    // count pass: the fix-up queue of the fast projection — (k << 8 | thread) of every point whose pixel the fast formula could not
+    // certify, and the reference formula's pixel for it
+    __shared__ uint16_t fixq[SCATTER ? 1 : PCL_BIN_PTS];
+    __shared__ uint32_t fixpix[SCATTER ? 1 : PCL_BIN_PTS];
+    __shared__ int fixn;
     const int cand = blockIdx.y;
     for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cnt[t] = 0;
+    if (threadIdx.x == 0) fixn = 0;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
     uint32_t pix[PER], dep[PER];
     uint32_t* __restrict__ pc = a.pcache + (int64_t)cand * 2 * a.n;
+    if constexpr (SCATTER) {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const int64_t i = first + (int64_t)k * PCL_BLOCK;
-        pix[k] = 0xffffffffu;                          // (row 65535 does not exist: H < 65536)
-        dep[k] = 0u;
-        if (i < a.n) {
-            if (SCATTER) {                             // the count pass's projection AND its dedup decision, read back
+        for (int k = 0; k < PER; k++) {
+            const int64_t i = first + (int64_t)k * PCL_BLOCK;
+            pix[k] = 0xffffffffu;                      // (row 65535 does not exist: H < 65536)
+            dep[k] = 0u;
+            if (i < a.n) {                             // the count pass's projection AND its dedup decision, read back
                 pix[k] = pc[i];
                 dep[k] = pc[a.n + i];
-            } else {
-                int row, col;
-                float d;
-                pcl_bin_project(a, a.poses + cand, i, row, col, d);
-                pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
-                dep[k] = __float_as_uint(d);
             }
         }
+    } else {
+        const PclPoseRec* __restrict__ pr = a.poses + cand;
+        int pend[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int64_t i = first + (int64_t)k * PCL_BLOCK;
+            pix[k] = 0xffffffffu;
+            dep[k] = 0u;
+            pend[k] = -1;
+            if (i < a.n) {
+                float qx = a.cloud[i] - pr->t[0], qy = a.cloud[a.stride + i] - pr->t[1], qz = a.cloud[2 * a.stride + i] - pr->t[2];
+                float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+                float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+                float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
+                int row, col;
+                dep[k] = __float_as_uint(pcl_point_depth(px, py, pz));
+                if (a.fast_margin_x > 0.f && pcl_pano_pixel_fast(px, py, pz, a.H, a.W, a.fast_margin_x, a.fast_margin_y, row, col)) {
+                    pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
+                } else {
+                    pend[k] = atomicAdd(&fixn, 1);
+                    fixq[pend[k]] = (uint16_t)((k << 8) | threadIdx.x);
+                }
+            }
+        }
+        __syncthreads();
+        const int nfix = fixn;
+        for (int e = threadIdx.x; e < nfix; e += PCL_BLOCK) {
+            const int k = fixq[e] >> 8, owner = fixq[e] & 255;
+            const int64_t i = (int64_t)blockIdx.x * PCL_BIN_PTS + owner + (int64_t)k * PCL_BLOCK;
+            int row, col;
+            float d;
+            pcl_bin_project(a, pr, i, row, col, d);    // the reference formula (two library atan2f)
+            fixpix[e] = ((uint32_t)row << 16) | (uint32_t)col;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (pend[k] >= 0) pix[k] = fixpix[pend[k]];
     }
     if (DEDUP && !SCATTER) {
 #pragma unroll
@@ -688,6 +758,11 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
         b.cap = cap;
         b.pcache = b.lists + (int64_t)ncand * 3 * cap;
+        // margins of the fast projection's certificate: 1.5e-6 x the image size (three times the error budget in the kernel's comment),
+        // at least 1e-3 pixel; PCL_BIN_EXACT=1: the reference formula for every point (A/B, and the cross-check of the certificate)
+        const bool exact_env = pcl_hist_env_int("PCL_BIN_EXACT", 0) != 0;
+        b.fast_margin_x = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)W);
+        b.fast_margin_y = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)H);
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
         // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)

@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -128,7 +129,8 @@ def main(d):
         # profiles/pipeline_roofs.json format (bench.py attaches it to also.pipeline*): per pipeline shape, per kernel, the binding roof
         keep = {k: {n: v for n, v in r.items() if n in ("avg_duration_us_kernel_trace", "binding_roof", "binding_frac", "roof_fractions", "hbm_bytes_per_launch",
                                                          "l2_hit_frac", "memory_side_atomic_requests", "valu_insts_per_launch", "dispatches_sampled")}
-                for k, r in roofs.items() if "binding_roof" in r and r.get("avg_duration_us_kernel_trace", 0) >= float(os.environ.get("PIPELINE_MIN_US", "8"))}
+                for k, r in roofs.items() if "binding_roof" in r and r.get("avg_duration_us_kernel_trace", 0) >= float(os.environ.get("PIPELINE_MIN_US", "4"))
+                and re.search(os.environ.get("PIPELINE_KERNELS", "zpass|zcache|pcl_loss|epilogue|fill_u32|pcl_trim|pcl_bin|resolve|pcl_select|pcl_hist|pcl_depth"), k)}
         json.dump({ptag: {"library_hash": library_hash(fn="pcl_library_hash"), "source": "profiles/%s" % os.environ.get("ROOF_SOURCE", os.path.basename(d.rstrip("/"))),
                           "command": os.environ.get("ROOF_CMD", ""), "kernels": keep}},
                   open(os.path.join(out, "pipeline_roofs.json"), "w"), indent=1, sort_keys=True)
