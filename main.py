@@ -52,13 +52,23 @@ def main():
             raise SystemExit("main.py needs an MI355X: torch.cuda.device_count() == 0")
         if backend == "nccl" and n_dev <= local_rank:
             raise SystemExit("local rank %d but only %d GPU(s) visible: one rank per GPU is required for the RCCL run" % (local_rank, n_dev))
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (bench.py)
         dev_index = local_rank if backend == "nccl" else local_rank % n_dev
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        # an explicit, short timeout: a rank that cannot reach the others ends with a reason instead of hanging for torch's 10-30 minutes
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PCL_DIST_TIMEOUT_S", "180")))
+        print("main.py rank %s/%s: device cuda:%d of %d visible, backend %s, HSA_ENABLE_IPC_MODE_LEGACY=%s" % (
+            os.environ["RANK"], os.environ["WORLD_SIZE"], dev_index, n_dev, backend, os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]), file=sys.stderr, flush=True)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as exc:                                      # noqa: BLE001
+            raise SystemExit("main.py rank %s: init_process_group(%s) FAILED: %s: %s" % (os.environ["RANK"], backend, type(exc).__name__, exc))
     from piccolo_amd import localize
     run = {"Synthetic": localize.localize_synthetic, "Stanford2D-3D-S": localize.localize_stanford,
            "OmniScenes": localize.localize_omniscenes}[cfg.dataset]
