@@ -68,6 +68,47 @@ def test_full_size_vs_oracle(ops, oracle, parity, cfg, n, H, W, B):
     assert np.array_equal(fwd[:, :2], out[:, :2])
 
 
+def test_full_size_depth_mask_vs_oracle(ops, oracle, parity):
+    """a12 at cfg 2's FULL size (1M points, 2048x1024), in the non-convex room the mask exists for: for six of the bench's starting
+    poses, the masked loss + mask count of ONE launch chain (z pass on the default depth grid with its occluder stride, lookup inside
+    the loss kernel) against the oracle — scatter-min over every stride-th packed point on the same grid, threshold, masked fp64 loss —
+    and the mask's recall / precision against analytic occlusion at the true pose.  Also with every point building the z-buffer."""
+    from piccolo_amd import synth
+    n, H, W, B = 1_000_000, 1024, 2048, 6
+    xyz, rgb = synth.furnished_room(n, 0)
+    X, C = T(xyz), T(rgb)
+    cloud = ops.Cloud(X, C)
+    order = cloud.order.cpu().numpy()
+    image_id = next(i for i in range(40) if not synth.inside_furniture(synth.gt_pose(i)[0]))
+    img, t_gt, ypr_gt = _pano(ops, X, C, H, W, image_id)
+    pano, img_host = ops.Pano(img), img.cpu().numpy()
+    trans, rot = synth.start_poses(t_gt, ypr_gt, B, seed=image_id)
+    trans[0], rot[0] = t_gt, ypr_gt                                   # pose 0 = the truth: where occlusion is checked analytically
+    for stride in (0, 1):                                             # 0: pcl_depth_default's choice (2 at 1M points)
+        dh, dw, tau, st = ops.default_depth(n, H, W, stride)
+        out = ops.sampling_loss(cloud, pano, T(trans), T(rot), with_grad=True, depth={"depth_stride": st}).cpu().numpy()
+        ref = np.empty((B, n), np.uint8)
+        for b in range(B):
+            cam = synth.transform_cloud(xyz, trans[b], rot[b])
+            zmin, _ = oracle.scatter_min_depth(cam[order[::st]], (dh, dw))
+            zmin = np.where(zmin == 0, np.inf, zmin)
+            row, col = oracle.pano_pixels(cam, (dh, dw))
+            ref[b] = np.linalg.norm(cam.astype(np.float64), axis=1) <= zmin[row.astype(np.int64) * dw + col].astype(np.float64) * (1 + tau)
+        o64 = oracle.sampling_loss(xyz, rgb, img_host, trans, rot, dtype=np.float64, grad=True, visible=ref)
+        tag = "cfg-2 size, depth grid %dx%d stride %d: " % (dw, dh, st)
+        flips = float(np.abs(out[:, 1] - o64["count"]).max())
+        parity(tag + "masked count vs oracle (points of 1M)", flips, 30)
+        parity(tag + "masked loss vs fp64 oracle", rel(out[:, 0], o64["loss"]), 1e-5 + 2.0 * flips / n)
+        parity(tag + "masked grad_t vs fp64 oracle", rel(out[:, 2:5], o64["grad_t"]), 1.5e-3)
+        parity(tag + "masked grad_ypr vs fp64 oracle", rel(out[:, 5:8], o64["grad_ypr"]), 1.5e-3)
+        occ = synth.occluded_by_furniture(xyz, t_gt)
+        hid = ref[0] == 0
+        tp = float((hid & occ).sum())
+        parity(tag + "1 - recall vs analytic occlusion at the true pose", 1 - tp / occ.sum(), 0.08)
+        parity(tag + "1 - precision", 1 - tp / max(hid.sum(), 1), 0.08)
+        assert 0.15 < occ.mean() < 0.3 and out[0, 1] < 0.9 * n
+
+
 def test_full_size_cfg2_vs_the_reference_itself(ops, oracle, parity):
     """G21: the REFERENCE's own BatchSamplingLoss + autograd at cfg 2's full size (1M points, 2048x1024, 32 poses; generated by
     tests/golden/gen_goldens.py in the build container, fp32 and fp64).  The yardstick of the full-size gradient tolerance is
