@@ -781,8 +781,9 @@ def test_depth_mask_vs_oracle_and_in_the_gd_loop(ops, oracle, parity):
     dh, dw, dtau, dst = ops.default_depth(len(xyz), H, W)
     assert (dh, dw, dst) == (40, 80, 1) and abs(dtau - 0.15) < 1e-6
     # (64 x 128 and the panorama's own grid: the LDS-window z pass; the narrower ones: the coarse-tile cache; stride 2 / 3: the
-    #  z-buffer from every 2nd / 3rd point of the packed cloud, every point tested)
-    for (gh, gw), tau, stride in (((dh, dw), dtau, 1), ((64, 128), 0.05, 1), ((H, W), 0.02, 1), ((24, 40), 0.1, 1), ((64, 128), 0.08, 2), ((32, 64), 0.12, 3)):
+    #  z-buffer from every 2nd / 3rd / 4th point of the packed cloud — the 16-byte-load forms of strides 2 and 4 and the generic one —,
+    #  every point tested)
+    for (gh, gw), tau, stride in (((dh, dw), dtau, 1), ((64, 128), 0.05, 1), ((H, W), 0.02, 1), ((24, 40), 0.1, 1), ((64, 128), 0.08, 2), ((32, 64), 0.12, 3), ((64, 128), 0.1, 4)):
         vis = ops.depth_mask(cloud, T(trans), T(rot), (gh, gw), tau=tau, stride=stride).cpu().numpy()
         assert vis.shape == (B, len(xyz))
         ref_all = np.empty((B, len(xyz)), np.uint8)
