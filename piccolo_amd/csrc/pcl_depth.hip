@@ -143,14 +143,23 @@ __device__ __forceinline__ void pcl_depth_block_points(const PclZArgs& a, int64_
 // the window's centre.  (First version: the block's MEAN cell, columns averaged as wrapped offsets: three wave reductions, LDS
 // atomics, a second barrier and two integer divisions per block, ~150 of the kernel's 700 VALU instructions per thread — the
 // window has room to spare for an off-centre anchor: a 2048-point run covers ~15 x 15 cells of the default grids, the window 32 x 64.)
-template <int TH, int TW, int PTS, int NT>
+// SECOND: a second, smaller window for what the first one misses.  A Morton run is compact in SPACE, not in the image: it may
+// straddle two walls, or lie near a pole — 4.5 % of the samples fall outside a 48 x 128 window at cfg 2, each one a memory-side atomic
+// of its own, and those were most of the launch's 34k requests per pose (CPU simulation, profiles/r05/experiments/zpass_windows.txt:
+// 44.6k direct + 8.5k flushed segments; with a 32 x 64 second window 6.1k + 9.3k).  The outside samples go to a small LDS queue
+// (cell, key); after the barrier the first queued sample's cell anchors window B and every queued sample is resolved by ONE thread
+// (one pass over at most NQ entries instead of a second sweep over all 2 PAIRS samples of every thread).
+template <int TH, int TW, int PTS, int NT, bool SECOND = false>
 __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
 {
     constexpr int PAIRS = PTS / (2 * NT);
+    constexpr int TH2 = 32, TW2 = 64, NQ = 768;            // window B, queue capacity (an overflowing sample goes to global memory at once)
     static_assert(PAIRS >= 2 && PAIRS % 2 == 0 && PTS % (2 * NT) == 0, "whole point quads per lane");
     static_assert((TW & (TW - 1)) == 0 && (TH * TW) % (4 * NT) == 0, "window: a power-of-two width, whole 16-byte words per thread");
     __shared__ __attribute__((aligned(16))) uint32_t tile[TH * TW];
-    __shared__ int org[2];
+    __shared__ __attribute__((aligned(16))) uint32_t tile2[SECOND ? TH2 * TW2 : 4];
+    __shared__ uint32_t qcell[SECOND ? NQ : 1], qkey[SECOND ? NQ : 1];
+    __shared__ int org[2], qn;
     int chunk, b;
     pcl_z_block(a.B, chunk, b);
     const int64_t base = (int64_t)chunk * PTS;                                 // (in occluder samples)
@@ -162,6 +171,13 @@ __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
         pcl_i4* t4 = reinterpret_cast<pcl_i4*>(tile);
 #pragma unroll
         for (int i = 0; i < TH * TW / 4 / NT; i++) t4[i * NT + threadIdx.x] = inf4;
+        if constexpr (SECOND) {
+            static_assert((TH2 * TW2) % (4 * NT) == 0, "window B: whole 16-byte words per thread");
+            pcl_i4* u4 = reinterpret_cast<pcl_i4*>(tile2);
+#pragma unroll
+            for (int i = 0; i < TH2 * TW2 / 4 / NT; i++) u4[i * NT + threadIdx.x] = inf4;
+            if (threadIdx.x == 0) qn = 0;
+        }
     }
     const int last = (int)a.nz - 1, Wd = a.g.Wd;
     int row[2 * PAIRS], col[2 * PAIRS];
@@ -183,9 +199,35 @@ __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
         const unsigned tr = (unsigned)(row[k] - r0);
         if (!full && key[k] == PCL_Z_INF) continue;
         if (tr < (unsigned)TH && (unsigned)tc < (unsigned)TW) atomicMin(&tile[tr * TW + tc], key[k]);
-        else atomicMin(&zb[(unsigned)pcl_depth_clamped_cell(row[k], col[k], a.g)], key[k]);
+        else {
+            const unsigned cell = (unsigned)pcl_depth_clamped_cell(row[k], col[k], a.g);
+            int pos = NQ;
+            if constexpr (SECOND) pos = atomicAdd(&qn, 1);
+            if (pos < NQ) { qcell[pos] = cell; qkey[pos] = key[k]; }
+            else atomicMin(&zb[cell], key[k]);
+        }
     }
     __syncthreads();
+    int r2 = 0, c2 = 0;
+    if constexpr (SECOND) {
+        const int nq = min(qn, NQ);
+        if (nq > 0) {                                                          // (block-uniform)
+            const unsigned cell0 = qcell[0];
+            r2 = (int)(cell0 / (unsigned)Wd) - TH2 / 2;
+            c2 = (int)(cell0 % (unsigned)Wd) - TW2 / 2;
+            c2 = c2 < 0 ? c2 + Wd : c2;
+            for (int e = threadIdx.x; e < nq; e += NT) {
+                const unsigned cell = qcell[e];
+                const int r = (int)(cell / (unsigned)Wd), c = (int)(cell % (unsigned)Wd);
+                int tc = c - c2;
+                tc = tc < 0 ? tc + Wd : tc;
+                const unsigned tr = (unsigned)(r - r2);
+                if (tr < (unsigned)TH2 && (unsigned)tc < (unsigned)TW2) atomicMin(&tile2[tr * TW2 + tc], qkey[e]);
+                else atomicMin(&zb[cell], qkey[e]);
+            }
+            __syncthreads();
+        }
+    }
     for (int i = threadIdx.x; i < TH * TW; i += NT) {
         const uint32_t v = tile[i];
         if (v == PCL_Z_INF) continue;
@@ -193,6 +235,18 @@ __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
         int c = c0 + (i & (TW - 1));
         c = c >= Wd ? c - Wd : c;
         atomicMin(&zb[(unsigned)pcl_depth_clamped_cell(r, c, a.g)], v);
+    }
+    if constexpr (SECOND) {
+        if (min(qn, NQ) > 0) {
+            for (int i = threadIdx.x; i < TH2 * TW2; i += NT) {
+                const uint32_t v = tile2[i];
+                if (v == PCL_Z_INF) continue;
+                const int r = r2 + i / TW2;
+                int c = c2 + (i & (TW2 - 1));
+                c = c >= Wd ? c - Wd : c;
+                atomicMin(&zb[(unsigned)pcl_depth_clamped_cell(r, c, a.g)], v);
+            }
+        }
     }
 }
 
@@ -378,7 +432,8 @@ int pcl_launch_zbuffers(const float* cloud, int64_t n, const PclPoseRec* poses, 
         else if (win_env == 2) hipLaunchKernelGGL((pcl_zpass_kernel<64, 128, 4096, 512>), grid, dim3(512), 0, s, a);
         else if (win_env == 3) hipLaunchKernelGGL((pcl_zpass_kernel<64, 128, 4096, 256>), grid, dim3(256), 0, s, a);
         else if (win_env == 4) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 512>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256>), grid, dim3(256), 0, s, a);
+        else if (win_env == 5) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256, true>), grid, dim3(256), 0, s, a);
     } else hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a, PTS);
     PCL_LAUNCH_CHECK();
     return 0;
