@@ -12,19 +12,21 @@
 // found 35 % of the occluded points (9 % at the shipped 167k points).  With >= 12 points per cell recall is 0.93-0.97; the price
 // of a coarse cell is that a surface seen at a grazing angle spans more than tau in depth inside one cell and hides its own far
 // side, so tau grows with the cell's angular size (pcl_depth_default: tau = 3.5 pi / Hd, clipped to [0.02, 0.15]: precision
-// 0.93-0.99).  1M points: 200 x 400 cells — make_pano's own default resolution (utils.py:134) — and tau = 0.055.
+// 0.93-0.99).  1M points, every point an occluder sample: 200 x 400 cells — make_pano's own default resolution (utils.py:134) — and
+// tau = 0.055; with the default occluder stride of 2: 144 x 288 cells, tau = 0.076, the same recall / precision (pcl_depth_default).
 //
-// Kernels (one launch each per GD iteration, all B poses):
-//   fill     : z-buffers <- +inf.  B x Hd x Wd words: 10 MB at cfg 2 (round 4: 268 MB), L2 / Infinity-Cache resident.
-//   z pass   : two points per lane, the loss kernel's own packed projection (pcl_rotate2 + pcl_angles2: the same instructions on
-//              the same inputs, so a point lands in the cell the loss kernel will look up).  A block takes PTS Morton-contiguous
-//              points of one pose: their cells form a compact patch, resolved with LDS atomicMin in a TH x TW window centred on
-//              the block's mean cell (columns wrap at the +-pi seam), then flushed: one global atomicMin per NON-EMPTY window cell.
-//              Global atomics execute at the memory side (MI355X_MICROARCH.md: not in L2), one 64-byte request per touched
-//              segment: with ~12 points per cell the block's 2048 points become ~200-400 cells in a few dozen row segments
-//              instead of ~2048 atomics.
-//   (lookup) : there is no mark pass and no byte mask in the GD loop: pcl_loss_kernel<.., VIS = 2, ..> reads the cell of each
-//              point while its texels are in flight (pcl_sample_device.h, pcl_project2_rotated<FMT, DEPTH>).
+// Kernels per GD iteration (all B poses; DESIGN.md section 4.5, the experiments behind every choice: profiles/EXPERIMENTS.md section 9):
+//   z pass   : pcl_zpass_kernel.  Occluder samples (every zstride-th packed point) quad-interleaved over the lanes, whole 16-byte loads;
+//              the loss kernel's own packed projection (pcl_rotate2 + pcl_angles2: the same instructions on the same inputs, so a
+//              sample lands in the cell the loss kernel will look up); a block's 4096 Morton-consecutive samples are resolved with LDS
+//              atomicMin in a 48 x 128-cell window anchored on the run's middle sample (columns wrap at the +-pi seam), the ones
+//              outside it through a small queue in a second 32 x 64 window, the rest (0.6 %) by one global atomic each; flush: one
+//              global atomicMin per NON-EMPTY window cell, 64 consecutive cells per wave instruction.  Global atomics execute at the
+//              memory side (MI355X_MICROARCH.md: not in L2), one 64-byte request per touched segment: 15k requests per pose.
+//              Grids narrower than a window: pcl_zcache_kernel (an LDS cache of coarse tiles); PCL_ZFORM=3: the untiled scatter (A/B).
+//   (lookup) : there is no mark pass and no byte mask in the GD loop: pcl_loss_kernel<.., VIS = 2, ..> reads the cell of each point
+//              while its texels are in flight (pcl_sample_device.h, pcl_project2_rotated<FMT, DEPTH>) and resets a slice of the OTHER
+//              z-buffer set for the next iteration — so no fill launch either, except in front of a call's first iteration.
 //   mark     : only for the stand-alone pcl_depth_mask (a byte mask for callers of pcl_sampling_loss's `visible`).
 #include <stdlib.h>
 
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
     }
 }
 
-// z pass, coarse-tile CACHE form (round 5; the default).  What the window form above loses: a Morton run is compact in SPACE, not
+// z pass, coarse-tile CACHE form (round 5; taken for grids narrower than a window).  What a single window loses: a Morton run is compact in SPACE, not
 // in the image — it may straddle two walls, or lie near a pole where a small patch spans every column — and every point outside
 // the window is one global atomic of its own: measured 5.7 % of the points at cfg 2 (simulated on the CPU with the oracle's pixels,
 // profiles/r05/experiments/zpass_windows.txt: 57k direct atomics + 10k flushed 64-byte segments per pose), and those 5.7 % were
@@ -259,7 +261,8 @@ __global__ void __launch_bounds__(NT) pcl_zpass_kernel(PclZArgs a)
 // of its tile with one compare-and-swap on the slot's tag (empty -> my tile), resolves into it with an LDS atomicMin when the tag
 // is its tile, and goes to the global z-buffer only when another tile holds the slot (S = 32, 2048 points: 0.7 % of the points;
 // S = 64, 4096 points: 0.7 %; total memory-side requests per pose 67k -> 18k / 16k).  Disjoint patches each get their own slots — no
-// anchor, no second pass.  Flush: each wave walks its share of the slots, skips the empty ones on the scalar unit, and issues the
+// anchor, no second pass.  On the wide default grids it LOSES to the window form (237 vs 195 us per iteration at cfg 2): the
+// compare-and-swap of 2048 samples on ~6 tags serialises in LDS.  Flush: each wave walks its share of the slots, skips the empty ones on the scalar unit, and issues the
 // claimed ones' cells as 64 consecutive cells per instruction = four whole 64-byte segments.
 template <int S, int PTS>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_zcache_kernel(PclZArgs a)
@@ -405,34 +408,27 @@ int pcl_launch_zbuffers(const float* cloud, int64_t n, const PclPoseRec* poses, 
     if (fill)
         hipLaunchKernelGGL(pcl_fill_u32x4_kernel, dim3((unsigned)(fill_blocks < 2048 ? fill_blocks : 2048)), dim3(PCL_BLOCK), 0, s, (pcl_i4*)zbuf, n4,
                            (int)PCL_Z_INF);
-    // Which z pass (PCL_ZFORM = 1 cache / 2 window / 3 direct forces one; PCL_ZSLOTS, PCL_ZPTS its shape: experiments).  Default:
-    // the 64 x 128-cell LDS window, 4096 points per block on the default (dense) grids, 2048 on grids so fine that most cells hold at
-    // most one point (round 3's tuning for a grid at the panorama's resolution); grids narrower than the window: the coarse-tile
-    // cache, which needs no minimum width.  Measured at cfg 2, default grid, per GD iteration (fill + z + loss + epilogue):
-    // window 64 x 128 / 4096 points 203 us, / 2048 points 226 us; cache 32 slots / 2048 points 237 us, 64 / 4096 247 us.
-    static const int form_env = pcl_depth_env("PCL_ZFORM", 0), slots_env = pcl_depth_env("PCL_ZSLOTS", 0), pts_env = pcl_depth_env("PCL_ZPTS", 0);
+    // Which z pass (PCL_ZFORM = 1 cache / 2 window / 3 untiled scatter forces one, PCL_ZSECOND=0 drops the second window: A/B).
+    // Default: the LDS window — 48 x 128 cells + a 32 x 64 second window, 4096 samples per block on dense grids (>= 2 samples per cell:
+    // every default grid); 64 x 128 cells, 2048 samples on grids so fine that most cells hold at most one sample (a grid at the
+    // panorama's resolution: round 3's tuning) — and the coarse-tile cache for grids narrower than a window.
+    // Measured at cfg 2, 400 x 200 grid, every point, per GD iteration (z + loss + epilogue; profiles/EXPERIMENTS.md section 9):
+    // window 48 x 128 + second window 195 us, without it 208, 64 x 128 206-209, 32 x 128 216, 64 x 64 225, 512-thread blocks 206,
+    // 2048 samples per block 226; cache 32 slots / 2048 samples 237, 64 / 4096 247; the first form (mean-centred 32 x 64 window,
+    // lane-major samples) 229.
+    static const int form_env = pcl_depth_env("PCL_ZFORM", 0), second_env = pcl_depth_env("PCL_ZSECOND", 1);
     const bool dense = (double)a.nz >= 2.0 * (double)g.Hd * (double)g.Wd;
-    int form = form_env ? form_env : (g.Wd >= 128 ? 2 : 1);
+    int form = form_env >= 1 && form_env <= 3 ? form_env : (g.Wd >= 128 ? 2 : 1);
     if (form == 2 && g.Wd < 128) form = 1;
     if (g.Hd >= 65536 * 8 || g.Wd >= 65536 * 16) form = 3;                      // (the cache's 16-bit tile coordinates)
-    const int slots = slots_env == 32 || slots_env == 64 ? slots_env : 32;
-    const int PTS = pts_env == 2048 || pts_env == 4096 ? pts_env : (form == 2 && dense ? 4096 : 2048);
+    const int PTS = form == 2 && dense ? 4096 : 2048;
     const int64_t chunks = (a.nz + PTS - 1) / PTS, chunks8 = (chunks + 7) / 8 * 8;
     if (chunks8 * B > 0x7fffffff) return PCL_EINVAL;
     const dim3 grid((unsigned)(chunks8 * B));
-    if (form == 1) {
-        if (slots == 32 && PTS == 2048) hipLaunchKernelGGL((pcl_zcache_kernel<32, 2048>), grid, dim3(PCL_BLOCK), 0, s, a);
-        else if (slots == 32) hipLaunchKernelGGL((pcl_zcache_kernel<32, 4096>), grid, dim3(PCL_BLOCK), 0, s, a);
-        else if (PTS == 2048) hipLaunchKernelGGL((pcl_zcache_kernel<64, 2048>), grid, dim3(PCL_BLOCK), 0, s, a);
-        else hipLaunchKernelGGL((pcl_zcache_kernel<64, 4096>), grid, dim3(PCL_BLOCK), 0, s, a);
-    } else if (form == 2) {
-        static const int win_env = pcl_depth_env("PCL_ZWIN", 0);               // experiments: other window shapes / block sizes at 4096 points
+    if (form == 1) hipLaunchKernelGGL((pcl_zcache_kernel<32, 2048>), grid, dim3(PCL_BLOCK), 0, s, a);
+    else if (form == 2) {
         if (PTS == 2048) hipLaunchKernelGGL((pcl_zpass_kernel<64, 128, 2048, 256>), grid, dim3(256), 0, s, a);
-        else if (win_env == 1) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256>), grid, dim3(256), 0, s, a);
-        else if (win_env == 2) hipLaunchKernelGGL((pcl_zpass_kernel<64, 128, 4096, 512>), grid, dim3(512), 0, s, a);
-        else if (win_env == 3) hipLaunchKernelGGL((pcl_zpass_kernel<64, 128, 4096, 256>), grid, dim3(256), 0, s, a);
-        else if (win_env == 4) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 512>), grid, dim3(512), 0, s, a);
-        else if (win_env == 5) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256>), grid, dim3(256), 0, s, a);
+        else if (!second_env) hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((pcl_zpass_kernel<48, 128, 4096, 256, true>), grid, dim3(256), 0, s, a);
     } else hipLaunchKernelGGL(pcl_depth_kernel<false>, grid, dim3(PCL_BLOCK), 0, s, a, PTS);
     PCL_LAUNCH_CHECK();

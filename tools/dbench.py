@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The depth passes alone for B candidate poses at cfg-2 size: pcl_depth_mask (pose setup + fill + z pass + mark) per call for a
 list of (grid, occluder stride) combinations; the mark pass is the same in all of them (every point is tested), so differences are
-the z pass's.   python tools/dbench.py [B]      (PCL_ZFORM / PCL_ZPTS / PCL_ZWIN: see csrc/pcl_depth.hip)"""
+the z pass's.   python tools/dbench.py [B]      (PCL_ZFORM / PCL_ZSECOND: see csrc/pcl_depth.hip)"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 """Depth-masked GD iteration (round 5 design: fill + z pass + loss launch with the in-kernel lookup) against the plain iteration,
 whole 100-iteration refinements timed from the host.   python tools/dgd_bench.py [B] [n_points]
-Env knobs of the z pass (experiments): PCL_ZTILE=1|2 (window 32x64 | 64x128), PCL_ZPASS_DIRECT=1 (untiled scatter)."""
+Env knobs of the z pass (experiments): PCL_ZFORM=1|2|3 (coarse-tile cache | LDS window | untiled scatter), PCL_ZSECOND=0 (no second window)."""
 import sys
 import time
 
