@@ -536,6 +536,28 @@ def test_bench_launches_its_own_ranks():
     assert d["roofline"]["frac"] > 0 and d["single_image"]["value"] > 0
 
 
+def test_bench_names_a_dead_rank():
+    """a rank that dies must not leave the job hanging.  Two self-launched gloo ranks, rank 1 leaves before its
+    first barrier (test hook), PCL_DIST_TIMEOUT_S = 20: the job ends within seconds, non-zero, without a JSON line — rank 0's barrier
+    fails inside the timeout with ONE line naming the collective and the reason (or torch.distributed.run, seeing rank 1's exit code,
+    ends rank 0 first and reports the failed rank itself)."""
+    import os
+    import subprocess
+    import sys
+    import time
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PCL_DIST_BACKEND="gloo", PCL_BENCH_TEST_DIE_RANK="1", PCL_DIST_TIMEOUT_S="20")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--workload", "cfg1", "--steps", "2", "--warmup", "1",
+                          "--no-also", "--no-cpu-baseline"], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0, out.stderr[-2000:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "leaving before the barrier" in out.stderr
+    assert "bench.py rank 0/2" in out.stderr and "FAILED" in out.stderr, out.stderr[-2000:]
+    assert time.time() - t0 < 300                                   # ended by the 20 s collective timeout, not by torch's 30 minutes
+
+
 def test_bench_launcher_relays_the_ranks_refusal():
     """The same command line with the default back end (RCCL: one GPU per rank) on a box with fewer GPUs than ranks: every
     rank refuses with the "visible" message, the launcher exits non-zero and prints no JSON line."""
