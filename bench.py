@@ -585,6 +585,47 @@ def pipeline_block(sc, n_images=3, num_input=32, num_intermediate=64):
             "median_t_err_m": float(np.median(rows[:, 2])), "median_r_err_deg": float(np.median(rows[:, 3]))}
 
 
+def host_buffers_block(sc, B=32, n_images=3):
+    """What `value` leaves out when the caller hands over HOST buffers (the product's Python surface accepts CPU tensors; the C ABI takes
+    device pointers only): per query image at cfg-2 size, one clock around upload + omniloc_batch (its packing launches included),
+    (a) image and start poses uploaded per call, the cloud tensors resident — a room's cloud is read once per room (localize.py:64-97),
+    (b) the cloud uploaded per call as well (a fresh tensor: Morton order, pack and quantile box are redone).  Pageable host memory."""
+    from piccolo_amd import omniloc as po
+
+    class Cfg:
+        lr, num_iter, patience, factor, out_of_room_quantile, num_input = LR, NUM_ITER, PATIENCE, FACTOR, QUANTILE, B
+    xyz_h, rgb_h = torch.from_numpy(sc.xyz), torch.from_numpy(sc.rgb)
+    host = []
+    for j in range(n_images + 1):
+        e = sc.image(3_000_000 + j, keep_img=True)
+        host.append((e["img"].cpu(), sc.starts(3_000_000 + j, B)[2]))
+        del e["img"]
+    rows = {"image": [], "cloud_and_image": []}
+    for mode in rows:
+        for j, (img_h, (tr_h, ro_h)) in enumerate(host):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            X, C = (xyz_h.to(sc.dev), rgb_h.to(sc.dev)) if mode == "cloud_and_image" else (sc.X, sc.C)
+            img = img_h.to(sc.dev)
+            tr, ro = torch.from_numpy(tr_h).to(sc.dev), torch.from_numpy(ro_h).to(sc.dev)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            po.omniloc_batch(img, X, C, tr, ro, Cfg(), {})
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if j:
+                rows[mode].append(((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+    a, b = np.array(rows["image"]), np.array(rows["cloud_and_image"])
+    mb = (xyz_h.numel() * xyz_h.element_size() + rgb_h.numel() * rgb_h.element_size()) / 1e6
+    img_mb = host[0][0].numel() * host[0][0].element_size() / 1e6
+    return {"what": "one image at a time, %d points, %dx%d, %d candidates x %d iterations; omniloc_batch from HOST buffers (pageable), medians over "
+                    "%d images; `value` of the line is measured with everything resident and is not this" % (sc.N, sc.W, sc.H, B, NUM_ITER, n_images),
+            "image_per_call": {"upload_MB": img_mb, "upload_ms": float(np.median(a[:, 0])), "total_ms": float(np.median(a[:, 1])),
+                               "candidate_poses_per_s": B / (float(np.median(a[:, 1])) * 1e-3)},
+            "cloud_and_image_per_call": {"upload_MB": mb + img_mb, "upload_ms": float(np.median(b[:, 0])), "total_ms": float(np.median(b[:, 1])),
+                                         "candidate_poses_per_s": B / (float(np.median(b[:, 1])) * 1e-3)}}
+
+
 def pipeline_images_block(sc, ipl=8, n_groups=3, num_input=6, num_intermediate=50):
     """The same pipeline for `ipl` query images of the room at a time, through the product's multi-image surface (what the dataset
     loops run with cfg images_per_launch): make_input_images (one trim launch over image x translation x rotation, one selection
@@ -898,6 +939,7 @@ def main():
             if (1_000_000, 1024, 2048) in scenes and world == 1:
                 also["pipeline"] = pipeline_block(scenes[(1_000_000, 1024, 2048)])
                 also["pipeline"]["kernel_roofs"] = pipeline_kernel_roofs("pipeline_cfg2")
+                also["host_buffers_cfg2"] = host_buffers_block(scenes[(1_000_000, 1024, 2048)])
             if (166_667, 1024, 2048) in scenes:          # the reference's shipped config end to end (stanford_parallel.ini)
                 also["pipeline_shipped"] = pipeline_block(scenes[(166_667, 1024, 2048)], num_input=6, num_intermediate=50)
                 also["pipeline_shipped"]["kernel_roofs"] = pipeline_kernel_roofs("pipeline_shipped")
