@@ -150,7 +150,27 @@ struct PclBinArgs {
     uint32_t* pcache;                  // [ncand][2][n]    round 5: every point's (pixel after the pre-dedup, depth bits), written by the
                                        // count pass and read back by the scatter pass, which used to project every point a second time
                                        // (two library atan2f per point: the pixels must match make_pano's bit for bit)
+    // ONE-PASS binning (round 5, pcl_bin_kernel<2>): no count pass, no scan.  A block's entries go to ITS OWN region of the candidate's
+    // list area (block b: entries [b * 4 PCL_BIN_PTS, (b + 1) * 4 PCL_BIN_PTS) — 4 n in all, the same exact worst case), grouped by tile
+    // with a block-local LDS prefix; a tile's list is then a handful of RUNS, one per block that touched it.
+    unsigned long long* stat;          // [ncand][nt]      runs << 32 | entries of the tile (one 64-bit atomic per (block, tile))
+    uint2* runs;                       // [ncand][nt][nb]  the tile's r-th run: (its first entry in the list area, entries of the tile in runs 0 .. r-1
+                                       //                  — the atomic's return value IS the exclusive prefix, in arrival order)
+    int4* heads;                       // [ncand][nt]      the resolve launch's order: (tile, runs, entries, 0) by decreasing entries
+    int nb;                            // blocks per candidate = ceil(n / PCL_BIN_PTS)
 };
+
+// inclusive prefix sum over the lanes of a wave (six ds_bpermute steps; the callers run it once per block)
+__device__ __forceinline__ int pcl_wave_scan_incl(int v)
+{
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
 
 // pixel of packed point i for pose pr, exactly as pcl_splat_poses_kernel computes it
 __device__ __forceinline__ void pcl_bin_project(const PclBinArgs& a, const PclPoseRec* __restrict__ pr, int64_t i, int& row, int& col, float& d)
@@ -228,9 +248,11 @@ __device__ __forceinline__ bool pcl_bin_dominated_by(uint32_t pix, uint32_t dep)
     return (int)((pa == pix) & (da < dep)) | (int)((pb == pix) & (db < dep));
 }
 
-template <bool SCATTER, bool DEDUP>
+// MODE 0: count, 1: scatter from the count pass's cache (the two-pass form, PCL_BIN_TWOPASS=1), 2: the one-pass form
+template <int MODE, bool DEDUP>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
 {
+    constexpr bool SCATTER = MODE == 1;
     constexpr int PER = PCL_BIN_PTS / PCL_BLOCK;
     extern __shared__ int lds[];                       // cnt[nt] (+ base[nt] when scattering)
     int* cnt = lds;
@@ -307,7 +329,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
             if (dom) pix[k] = 0xffffffffu;             // a nearer point owns this pixel (the compares above all saw the originals:
         }                                              // k is a different point set per trip)
     }
-    if (!SCATTER) {
+    if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int64_t i = first + (int64_t)k * PCL_BLOCK;
@@ -327,17 +349,36 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
         }
     }
     __syncthreads();
-    if (!SCATTER) {
+    if (MODE == 0) {
         int* g = a.counts + (int64_t)cand * a.nt;
         for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK)
             if (cnt[t]) atomicAdd(&g[t], cnt[t]);
         return;
     }
-    int* cur = a.cursors + (int64_t)cand * a.nt;
-    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
-        int c = cnt[t];
-        base[t] = c ? atomicAdd(&cur[t], c) : 0;       // this block's range inside the tile's list
-        cnt[t] = 0;                                    // becomes the block-local cursor
+    const int per_thread = (a.nt + PCL_BLOCK - 1) / PCL_BLOCK, t_lo = (int)threadIdx.x * per_thread, t_hi = min(t_lo + per_thread, a.nt);
+    if (MODE == 1) {
+        int* cur = a.cursors + (int64_t)cand * a.nt;
+        for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
+            int c = cnt[t];
+            base[t] = c ? atomicAdd(&cur[t], c) : 0;   // this block's range inside the tile's list
+            cnt[t] = 0;                                // becomes the block-local cursor
+        }
+    } else {
+        // block-local exclusive prefix of the tile counters: thread i owns counters [i per_thread, (i + 1) per_thread)
+        __shared__ int wave_total[PCL_BLOCK / PCL_WAVE];
+        int s = 0;
+        for (int t = t_lo; t < t_hi; t++) s += cnt[t];
+        const int incl = pcl_wave_scan_incl(s);
+        if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int run = incl - s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_total[w];
+        for (int t = t_lo; t < t_hi; t++) {
+            const int c = cnt[t];
+            base[t] = run + (int)blockIdx.x * (4 * PCL_BIN_PTS);   // first entry of this (block, tile) run inside the candidate's list area
+            run += c;
+            cnt[t] = 0;
+        }
     }
     __syncthreads();
     const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
@@ -349,12 +390,25 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
         for (int j = 0; j < 4; j++) {
             const int t = tiles[k][j];
             if (t < 0) continue;
-            const int pos = off[t] + base[t] + atomicAdd(&cnt[t], 1);
+            const int pos = (MODE == 1 ? off[t] : 0) + base[t] + atomicAdd(&cnt[t], 1);
             // the projection travels with the entry: the resolve kernel reads 12 coalesced bytes per entry instead of chasing
             // slot -> x, y, z and projecting a third time
             list[pos] = pix[k];
             list[a.cap + pos] = dep[k];
             list[2 * a.cap + pos] = (uint32_t)i;
+        }
+    }
+    if (MODE == 2) {
+        // publish the runs LAST: the atomics' round trips then delay nobody (the counters hold the run lengths again once every entry
+        // has been written)
+        __syncthreads();
+        unsigned long long* st = a.stat + (int64_t)cand * a.nt;
+        uint2* runs = a.runs + (int64_t)cand * a.nt * a.nb;
+        for (int t = t_lo; t < t_hi; t++) {
+            const int c = cnt[t];
+            if (!c) continue;
+            const unsigned long long old = atomicAdd(&st[t], (1ull << 32) | (unsigned long long)c);
+            runs[(int64_t)t * a.nb + (int64_t)(old >> 32)] = make_uint2((uint32_t)base[t], (uint32_t)old);   // (first entry, tile entries before it)
         }
     }
 }
@@ -397,6 +451,38 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_scan_kernel(PclBinArgs a)
     }
 }
 
+// one-pass form: the resolve launch's order for one candidate — tiles by decreasing entry count (ties by index), each with its run count.
+// A block ranks 64 tiles, each wave against a quarter of the counts (a block per candidate with every thread walking all nt counts was
+// 29 us of LDS latency for 512 tiles, as much as the scan it replaced).
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_rank_kernel(PclBinArgs a)
+{
+    extern __shared__ int cl[];                        // [nt rounded up to 4] counts, then [4][64] partial ranks
+    const int cand = blockIdx.x, nt4 = (a.nt + 3) & ~3;
+    int* part = cl + nt4;
+    const uint2* __restrict__ st = (const uint2*)(a.stat + (int64_t)cand * a.nt);      // .x = entries, .y = runs
+    for (int u = threadIdx.x; u < nt4; u += PCL_BLOCK) cl[u] = u < a.nt ? (int)st[u].x : -1;      // (-1: ranks behind every tile)
+    __syncthreads();
+    const int t = (int)blockIdx.y * 64 + (int)(threadIdx.x & 63), seg = (int)(threadIdx.x >> 6);
+    const int per = ((nt4 >> 2) + 3) / 4 * 4;          // counts per wave, a multiple of four
+    const int u_lo = min(seg * per, nt4), u_hi = min(u_lo + per, nt4);
+    const int c = t < a.nt ? cl[t] : 0;
+    int rank = 0;
+#pragma unroll 4
+    for (int u = u_lo; u < u_hi; u += 4) {
+        const int v0 = cl[u], v1 = cl[u + 1], v2 = cl[u + 2], v3 = cl[u + 3];
+        rank += (v0 > c || (v0 == c && u < t)) ? 1 : 0;
+        rank += (v1 > c || (v1 == c && u + 1 < t)) ? 1 : 0;
+        rank += (v2 > c || (v2 == c && u + 2 < t)) ? 1 : 0;
+        rank += (v3 > c || (v3 == c && u + 3 < t)) ? 1 : 0;
+    }
+    part[threadIdx.x] = rank;
+    __syncthreads();
+    if (seg == 0 && t < a.nt) {
+        rank = part[threadIdx.x] + part[64 + threadIdx.x] + part[128 + threadIdx.x] + part[192 + threadIdx.x];
+        a.heads[(int64_t)cand * a.nt + rank] = make_int4(t, (int)st[t].y, c, 0);
+    }
+}
+
 // One workgroup per (tile, candidate): resolve the tile in LDS (same keys as the splat path), then histogram the winners of
 // the pixels where the query image is not black into the block histograms (LDS for the up to 2 x 2 histogram blocks a tile
 // overlaps; tiny blocks — more than that per tile — go to the global counters directly).
@@ -423,20 +509,38 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // candidate fastest: workgroups are handed out x first, so rank 0 — the heaviest tile — of EVERY candidate starts before
     // any rank-1 tile (tile-major launches started the last candidate's heaviest tile at 94 % of the launch)
     const int cand = blockIdx.x;
-    const int t = a.order[(int64_t)cand * a.nt + blockIdx.y];          // heaviest tiles first
+    const bool onepass = a.heads != nullptr;
+    int t, e0, e1, nruns = 0;
+    if (onepass) {
+        const int4 hd = a.heads[(int64_t)cand * a.nt + blockIdx.y];    // heaviest tiles first
+        t = hd.x; nruns = hd.y; e0 = 0; e1 = hd.z;
+    } else {
+        t = a.order[(int64_t)cand * a.nt + blockIdx.y];
+        const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
+        e0 = off[t]; e1 = off[t + 1];
+    }
 #ifdef PCL_BLOCK_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
     const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
     const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
-    const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
     const uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
-    const int e0 = off[t], e1 = off[t + 1];
     if (e0 == e1) return;                              // nothing projects here (or the tile is outside the scored rows)
+    // One-pass lists: the tile's entries are `nruns` runs (one per bin block that touched the tile) somewhere in the candidate's list
+    // area.  Entry e of the tile lives at run_first[r] + (e - run_pre[r]) for the last run r with run_pre[r] <= e; the runs' (first
+    // entry, entries of the tile before the run) are staged in LDS, every lane finds its run by bisection.  The first PCL_RESOLVE_THREADS
+    // runs are requested here, before the tile is initialised (their latency hides behind it); a tile fed by more blocks than that
+    // goes through in batches, e0 .. e1 = the entries of one batch.
+    __shared__ uint32_t run_first[PCL_RESOLVE_THREADS], run_pre[PCL_RESOLVE_THREADS];
+    const uint2* runs = onepass ? a.runs + ((int64_t)cand * a.nt + t) * a.nb : nullptr;
+    const int total = e1;
+    uint2 run0 = make_uint2(0u, 0u);
+    if (onepass && (int)threadIdx.x < nruns) run0 = runs[threadIdx.x];
     const int r_org = ty * PCL_TS - 2, c_org = tx * PCL_TS - 2;
     for (int i = threadIdx.x; i < TW * TW; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
     for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
+    if (onepass) { run_first[threadIdx.x] = run0.x; run_pre[threadIdx.x] = run0.y; }
     __syncthreads();
     // The list is walked in slabs of PCL_RESOLVE_THREADS entries staged through LDS: the loads are coalesced (lane = entry),
     // but the entries of a list are Morton neighbours — 64 consecutive ones land on a handful of pixels, and LDS atomics of
@@ -446,19 +550,41 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // 17.6 us; with the atomics compiled out 13.7, with the tile reads out as well 9.9 — over half of the walk is the list
     // itself arriving from memory (12 B per entry, 2.5 TB/s over the whole launch).
     __shared__ uint32_t slab[3][PCL_RESOLVE_THREADS];
+    const int nbatch = onepass ? (nruns + PCL_RESOLVE_THREADS - 1) / PCL_RESOLVE_THREADS : 1;
+    const int j = ((int)threadIdx.x * 17) & (PCL_RESOLVE_THREADS - 1);
+  for (int batch = 0; batch < nbatch; batch++) {
+    int nr = 0;
+    if (onepass) {
+        const int r0 = batch * PCL_RESOLVE_THREADS;
+        nr = min(PCL_RESOLVE_THREADS, nruns - r0);
+        if (batch > 0) {                               // (the previous batch's last slab trip ended with a barrier: the tables are free)
+            if ((int)threadIdx.x < nr) { const uint2 r = runs[r0 + (int)threadIdx.x]; run_first[threadIdx.x] = r.x; run_pre[threadIdx.x] = r.y; }
+            __syncthreads();
+        }
+        e0 = (int)run_pre[0];
+        e1 = r0 + nr < nruns ? (int)runs[r0 + nr].y : total;
+    }
+    auto entry_at = [&](int e) -> int64_t {
+        if (!onepass) return (int64_t)e;
+        int lo = 0, hi = nr;                           // the last run that starts at or before e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)run_pre[mid] <= e) lo = mid; else hi = mid;
+        }
+        return (int64_t)run_first[lo] + (e - (int)run_pre[lo]);
+    };
     uint32_t npix = 0xffffffffu, ndep = 0u, nid = 0u;
     {
         const int e = e0 + (int)threadIdx.x;
-        if (e < e1) { npix = list[e]; ndep = list[a.cap + e]; nid = list[2 * a.cap + e]; }
+        if (e < e1) { const int64_t q = entry_at(e); npix = list[q]; ndep = list[a.cap + q]; nid = list[2 * a.cap + q]; }
     }
-    const int j = ((int)threadIdx.x * 17) & (PCL_RESOLVE_THREADS - 1);
     for (int base = e0; base < e1; base += PCL_RESOLVE_THREADS) {
         slab[0][threadIdx.x] = npix; slab[1][threadIdx.x] = ndep; slab[2][threadIdx.x] = nid;
         __syncthreads();
         {
             const int e = base + PCL_RESOLVE_THREADS + (int)threadIdx.x;
             npix = 0xffffffffu;
-            if (e < e1) { npix = list[e]; ndep = list[a.cap + e]; nid = list[2 * a.cap + e]; }
+            if (e < e1) { const int64_t q = entry_at(e); npix = list[q]; ndep = list[a.cap + q]; nid = list[2 * a.cap + q]; }
         }
         const uint32_t pix = slab[0][j], dbits = slab[1][j], i = slab[2][j];
         if (pix != 0xffffffffu) {
@@ -485,6 +611,7 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
         }
         __syncthreads();                               // the slab is overwritten at the top of the next trip
     }
+  }
     __syncthreads();
 #ifdef PCL_BLOCK_TRACE
     const unsigned long long trace_t1 = __builtin_amdgcn_s_memrealtime();
@@ -673,7 +800,9 @@ static size_t hist_render_bytes(int64_t n, int H, int W)
     if (n <= 0) return zb;
     const size_t nt = (size_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
     if (!hist_binned_ok(n, H, W)) return zb;       // the launch would take the splat path anyway: no lists to hold
-    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12 + (size_t)n * 8;      // bookkeeping + lists + the projection cache
+    const size_t nb = (size_t)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS);
+    // bookkeeping + lists + the two-pass form's projection cache + the one-pass form's tile statistics, launch order and run tables
+    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12 + (size_t)n * 8 + nt * (8 + 16 + nb * 8) + 64;
     return binned > zb ? binned : zb;
 }
 
@@ -758,6 +887,13 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
         b.cap = cap;
         b.pcache = b.lists + (int64_t)ncand * 3 * cap;
+        b.nb = (int)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS);
+        const bool twopass = pcl_hist_env_int("PCL_BIN_TWOPASS", 0) != 0;      // (A/B and cross-check: count -> scan -> scatter)
+        char* tail = (char*)(b.pcache + (int64_t)ncand * 2 * n);
+        tail += (16 - ((uintptr_t)tail & 15)) & 15;
+        b.heads = twopass ? nullptr : (int4*)tail;
+        b.stat = (unsigned long long*)(tail + (size_t)ncand * nt * sizeof(int4));
+        b.runs = (uint2*)(b.stat + (size_t)ncand * nt);
         // margins of the fast projection's certificate: 1.5e-6 x the image size (three times the error budget in the kernel's comment),
         // at least 1e-3 pixel; PCL_BIN_EXACT=1: the reference formula for every point (A/B, and the cross-check of the certificate)
         const bool exact_env = pcl_hist_env_int("PCL_BIN_EXACT", 0) != 0;
@@ -766,7 +902,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
         // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)
-        me = hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s);
+        me = twopass ? hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s) : hipMemsetAsync(b.stat, 0, (size_t)ncand * nt * sizeof(unsigned long long), s);
         if (me != hipSuccess) return (int)me;
         hipLaunchKernelGGL(pcl_hist_codes_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0, s, cloud, n, stride, codes);
         dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
@@ -776,14 +912,18 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         // nothing is dropped and the compares cost 9 us per 50 candidates — hence the density gate.  PCL_BIN_DEDUP=0 / 1 forces.
         const int dedup_env = pcl_hist_env_int("PCL_BIN_DEDUP", -1);
         const bool dedup = dedup_env >= 0 ? dedup_env != 0 : 4 * n >= (int64_t)H * W;
-        if (dedup) {
-            hipLaunchKernelGGL((pcl_bin_kernel<false, true>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int) + win_bytes, s, b);
+        if (!twopass) {
+            if (dedup) hipLaunchKernelGGL((pcl_bin_kernel<2, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+            else hipLaunchKernelGGL((pcl_bin_kernel<2, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+            hipLaunchKernelGGL(pcl_bin_rank_kernel, dim3(ncand, (nt + 63) / 64), dim3(PCL_BLOCK), (size_t)(((nt + 3) & ~3) + PCL_BLOCK) * sizeof(int), s, b);
+        } else if (dedup) {
+            hipLaunchKernelGGL((pcl_bin_kernel<0, true>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int) + win_bytes, s, b);
             hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-            hipLaunchKernelGGL((pcl_bin_kernel<true, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int) + win_bytes, s, b);
+            hipLaunchKernelGGL((pcl_bin_kernel<1, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int) + win_bytes, s, b);
         } else {
-            hipLaunchKernelGGL((pcl_bin_kernel<false, false>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
+            hipLaunchKernelGGL((pcl_bin_kernel<0, false>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
             hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-            hipLaunchKernelGGL((pcl_bin_kernel<true, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+            hipLaunchKernelGGL((pcl_bin_kernel<1, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
         }
         const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
         const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
