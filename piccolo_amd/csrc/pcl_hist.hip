@@ -1,6 +1,6 @@
 // pcl_hist.hip — the second trimming stage of the initialisation (reference utils.py:510-588, color_utils.py:68-144)
 // for a BATCH of candidate poses.  Two renderers feed the same histogram counters (bit-identical results):
-//   tile-binned (default, round 2): pcl_bin_kernel<false> / pcl_bin_scan_kernel / pcl_bin_kernel<true> bin every candidate's
+//   tile-binned (default, round 2; one pass since round 5): pcl_bin_kernel / pcl_bin_rank_kernel bin every candidate's
 //                               points by the 64 x 64-pixel tiles their 3 x 3 splats touch; pcl_tile_resolve_hist_kernel
 //                               resolves one tile per workgroup in LDS and histograms the winners — no z-buffer in HBM;
 //   z-buffer splat (round 1, kept for workspaces sized without n and as the cross-check):
@@ -120,8 +120,8 @@ __device__ inline int pcl_hist_code(float r, float g, float b)
 // The splat path above pays ~2 global 64-bit atomics per rendered pixel (the LDS windows of neighbouring blocks overlap),
 // a 16 MB-per-candidate z-buffer fill and a second pass that reads it back (rocprofv3, profiles/r02/e_init_stage_*: splat 659
 // us per 16 candidates with the VALUs 34 % busy, 530 MB of atomic traffic; fill 49 us; accumulate 123 us).  Here every
-// candidate's points are first BINNED by the 64 x 64-pixel image tile(s) their 3 x 3 splat touches (count -> scan ->
-// scatter of packed point slots, block-aggregated in LDS: one global atomic per (block, tile)); then one workgroup per
+// candidate's points are first BINNED by the 64 x 64-pixel image tile(s) their 3 x 3 splat touches (grouped by tile inside
+// the block with an LDS prefix: one global atomic per (block, tile)); then one workgroup per
 // (tile, candidate) resolves its tile completely in LDS with the very same 64-bit priority keys and histograms the winners
 // straight into the block histograms.  Same keys, same winners, same integer counts as the splat path (bit-identical scores,
 // tests/test_hip_harness.py).  The point lists live where the z-buffer would have been.
@@ -140,19 +140,15 @@ struct PclBinArgs {
     int H, W, ntx, nt;                 // tiles per row, tiles per image
     int ty_lo, ty_hi;                  // tile rows that hold pixels of the scored block rows 1 .. nsh-2 (utils.py:556): the
                                        // tiles above and below are never binned — half the image at num_split_h = 4
-    int* counts;                       // [ncand][nt]      points (with multiplicity) per tile
-    int* offsets;                      // [ncand][nt + 1]  exclusive scan of counts
-    int* cursors;                      // [ncand][nt]      scatter cursors
-    int* order;                        // [ncand][nt]      tiles by decreasing count: the resolve kernel's launch order
     uint32_t* lists;                   // [ncand][3][cap]  per entry: pixel (row << 16 | col), depth bits, packed point slot
     int64_t cap;                       // entries per candidate (4 n: a 3 x 3 splat touches at most four tiles)
-    float fast_margin_x, fast_margin_y; // count pass: a fast-formula pixel coordinate farther than this from an integer is certain (0: reference formula for all)
-    uint32_t* pcache;                  // [ncand][2][n]    round 5: every point's (pixel after the pre-dedup, depth bits), written by the
-                                       // count pass and read back by the scatter pass, which used to project every point a second time
-                                       // (two library atan2f per point: the pixels must match make_pano's bit for bit)
-    // ONE-PASS binning (round 5, pcl_bin_kernel<2>): no count pass, no scan.  A block's entries go to ITS OWN region of the candidate's
-    // list area (block b: entries [b * 4 PCL_BIN_PTS, (b + 1) * 4 PCL_BIN_PTS) — 4 n in all, the same exact worst case), grouped by tile
-    // with a block-local LDS prefix; a tile's list is then a handful of RUNS, one per block that touched it.
+    float fast_margin_x, fast_margin_y; // a fast-formula pixel coordinate farther than this from an integer is certain (0: reference formula for all)
+    // ONE-PASS binning (round 5).  Rounds 2-4 counted (one projection), scanned and scattered (a second projection; round 5 first cached
+    // the count pass's pixels: 8 B per point and candidate written and read back).  Now a block's entries go to ITS OWN region of the
+    // candidate's list area (block b: entries [b * 4 PCL_BIN_PTS, (b + 1) * 4 PCL_BIN_PTS) — 4 n in all, the same exact worst case),
+    // grouped by tile with a block-local LDS prefix; a tile's list is then a handful of RUNS, one per block that touched it.  Measured
+    // A/B in one build (tools/hist_stage_bench.py): 1.23 -> 1.06 ms per 64 candidates at 1M points, 0.42 -> 0.37 per 50 at 167k
+    // (count 342 + scan 32 + scatter 268 -> bin 435 + rank 7 us; the resolve kernel pays 492 -> 531 for finding its entries run by run).
     unsigned long long* stat;          // [ncand][nt]      runs << 32 | entries of the tile (one 64-bit atomic per (block, tile))
     uint2* runs;                       // [ncand][nt][nb]  the tile's r-th run: (its first entry in the list area, entries of the tile in runs 0 .. r-1
                                        //                  — the atomic's return value IS the exclusive prefix, in arrival order)
@@ -220,10 +216,9 @@ __device__ __forceinline__ void pcl_bin_tiles(int row, int col, int H, int W, in
     tiles[3] = bot && two ? rb * ntx + cb : -1;
 }
 
-// SCATTER = false: count; true: reserve a range per (block, tile) and write the entries.  A block takes PCL_BIN_PTS
-// consecutive (Morton-ordered) points: the zeroing and the flush of the nt LDS counters are per block, and with 256 points
-// per block they were most of the kernel (114 / 189 us per 16 candidates at 1M points; a wave-aggregated LDS add instead of
-// one atomic per lane did not help: 130 / 213 us).
+// A block takes PCL_BIN_PTS consecutive (Morton-ordered) points: the zeroing and the prefix of the nt LDS counters are per block, and
+// with 256 points per block they were most of the kernel (round 2: 114 / 189 us per 16 candidates at 1M points; a wave-aggregated LDS
+// add instead of one atomic per lane did not help: 130 / 213 us).
 #define PCL_BIN_PTS 2048
 // Pre-dedup (round 4).  Two points of one candidate with the SAME centre pixel splat the same nine cells with the same pass
 // priorities, so the farther one loses every one of them: it can be dropped before it is ever listed.  Morton order puts the
@@ -231,7 +226,7 @@ __device__ __forceinline__ void pcl_bin_tiles(int row, int col, int H, int W, in
 // 68 000 list entries (30x the mean: the resolve kernel's tail).  Consecutive lanes hold consecutive Morton points, so a lane
 // compares its (pixel, depth) with the lanes up to PCL_BIN_NEIGH places to either side of it in its row of 16 (DPP row shifts: no
 // LDS, no barrier) and drops out when one of them has the same pixel and a strictly smaller depth.  (Equal depths: both stay.)
-// Count and scatter pass take the same decisions, and the surviving keys are untouched: every cell's winner, hence every score,
+// The surviving keys are untouched: every cell's winner, hence every score,
 // is bit-identical to the undeduplicated lists (tests: against the z-buffer splat path, which never dedups).  A first version
 // resolved the block's pixels in a 96 x 96 LDS window (exact within the block): resolve 613 -> 454 us per 64 candidates at 1M
 // points, but 138 / 128 us MORE in the count / scatter kernels (window fill, two barriers, 40 KB of LDS) — a net loss.
@@ -248,78 +243,63 @@ __device__ __forceinline__ bool pcl_bin_dominated_by(uint32_t pix, uint32_t dep)
     return (int)((pa == pix) & (da < dep)) | (int)((pb == pix) & (db < dep));
 }
 
-// MODE 0: count, 1: scatter from the count pass's cache (the two-pass form, PCL_BIN_TWOPASS=1), 2: the one-pass form
-template <int MODE, bool DEDUP>
+template <bool DEDUP>
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
 {
-    constexpr bool SCATTER = MODE == 1;
     constexpr int PER = PCL_BIN_PTS / PCL_BLOCK;
-    extern __shared__ int lds[];                       // cnt[nt] (+ base[nt] when scattering)
+    extern __shared__ int lds[];                       // cnt[nt], base[nt]
     int* cnt = lds;
     int* base = lds + a.nt;
-    // count pass: the fix-up queue of the fast projection — (k << 8 | thread) of every point whose pixel the fast formula could not
-    // certify, and the reference formula's pixel for it
-    __shared__ uint16_t fixq[SCATTER ? 1 : PCL_BIN_PTS];
-    __shared__ uint32_t fixpix[SCATTER ? 1 : PCL_BIN_PTS];
+    // the fix-up queue of the fast projection — (k << 8 | thread) of every point whose pixel the fast formula could not certify, and
+    // the reference formula's pixel for it
+    __shared__ uint16_t fixq[PCL_BIN_PTS];
+    __shared__ uint32_t fixpix[PCL_BIN_PTS];
     __shared__ int fixn;
+    __shared__ int wave_total[PCL_BLOCK / PCL_WAVE];
     const int cand = blockIdx.y;
     for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cnt[t] = 0;
     if (threadIdx.x == 0) fixn = 0;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * PCL_BIN_PTS + threadIdx.x;
     uint32_t pix[PER], dep[PER];
-    uint32_t* __restrict__ pc = a.pcache + (int64_t)cand * 2 * a.n;
-    if constexpr (SCATTER) {
+    const PclPoseRec* __restrict__ pr = a.poses + cand;
+    int pend[PER];
 #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int64_t i = first + (int64_t)k * PCL_BLOCK;
-            pix[k] = 0xffffffffu;                      // (row 65535 does not exist: H < 65536)
-            dep[k] = 0u;
-            if (i < a.n) {                             // the count pass's projection AND its dedup decision, read back
-                pix[k] = pc[i];
-                dep[k] = pc[a.n + i];
-            }
-        }
-    } else {
-        const PclPoseRec* __restrict__ pr = a.poses + cand;
-        int pend[PER];
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int64_t i = first + (int64_t)k * PCL_BLOCK;
-            pix[k] = 0xffffffffu;
-            dep[k] = 0u;
-            pend[k] = -1;
-            if (i < a.n) {
-                float qx = a.cloud[i] - pr->t[0], qy = a.cloud[a.stride + i] - pr->t[1], qz = a.cloud[2 * a.stride + i] - pr->t[2];
-                float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
-                float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
-                float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
-                int row, col;
-                dep[k] = __float_as_uint(pcl_point_depth(px, py, pz));
-                if (a.fast_margin_x > 0.f && pcl_pano_pixel_fast(px, py, pz, a.H, a.W, a.fast_margin_x, a.fast_margin_y, row, col)) {
-                    pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
-                } else {
-                    pend[k] = atomicAdd(&fixn, 1);
-                    fixq[pend[k]] = (uint16_t)((k << 8) | threadIdx.x);
-                }
-            }
-        }
-        __syncthreads();
-        const int nfix = fixn;
-        for (int e = threadIdx.x; e < nfix; e += PCL_BLOCK) {
-            const int k = fixq[e] >> 8, owner = fixq[e] & 255;
-            const int64_t i = (int64_t)blockIdx.x * PCL_BIN_PTS + owner + (int64_t)k * PCL_BLOCK;
+    for (int k = 0; k < PER; k++) {
+        const int64_t i = first + (int64_t)k * PCL_BLOCK;
+        pix[k] = 0xffffffffu;                          // (row 65535 does not exist: H < 65536)
+        dep[k] = 0u;
+        pend[k] = -1;
+        if (i < a.n) {
+            float qx = a.cloud[i] - pr->t[0], qy = a.cloud[a.stride + i] - pr->t[1], qz = a.cloud[2 * a.stride + i] - pr->t[2];
+            float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
+            float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
+            float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
             int row, col;
-            float d;
-            pcl_bin_project(a, pr, i, row, col, d);    // the reference formula (two library atan2f)
-            fixpix[e] = ((uint32_t)row << 16) | (uint32_t)col;
+            dep[k] = __float_as_uint(pcl_point_depth(px, py, pz));
+            if (a.fast_margin_x > 0.f && pcl_pano_pixel_fast(px, py, pz, a.H, a.W, a.fast_margin_x, a.fast_margin_y, row, col)) {
+                pix[k] = ((uint32_t)row << 16) | (uint32_t)col;
+            } else {
+                pend[k] = atomicAdd(&fixn, 1);
+                fixq[pend[k]] = (uint16_t)((k << 8) | threadIdx.x);
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PER; k++)
-            if (pend[k] >= 0) pix[k] = fixpix[pend[k]];
     }
-    if (DEDUP && !SCATTER) {
+    __syncthreads();
+    const int nfix = fixn;
+    for (int e = threadIdx.x; e < nfix; e += PCL_BLOCK) {
+        const int k = fixq[e] >> 8, owner = fixq[e] & 255;
+        const int64_t i = (int64_t)blockIdx.x * PCL_BIN_PTS + owner + (int64_t)k * PCL_BLOCK;
+        int row, col;
+        float d;
+        pcl_bin_project(a, pr, i, row, col, d);        // the reference formula (two library atan2f)
+        fixpix[e] = ((uint32_t)row << 16) | (uint32_t)col;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (pend[k] >= 0) pix[k] = fixpix[pend[k]];
+    if (DEDUP) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             // (`|`, not `||`: every lane takes part in every DPP read — a short-circuit would switch source lanes off)
@@ -328,13 +308,6 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
             if (PCL_BIN_NEIGH >= 4) dom |= (int)pcl_bin_dominated_by<4>(pix[k], dep[k]);
             if (dom) pix[k] = 0xffffffffu;             // a nearer point owns this pixel (the compares above all saw the originals:
         }                                              // k is a different point set per trip)
-    }
-    if (MODE == 0) {
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const int64_t i = first + (int64_t)k * PCL_BLOCK;
-            if (i < a.n) { pc[i] = pix[k]; pc[a.n + i] = dep[k]; }
-        }
     }
     int tiles[PER][4];
 #pragma unroll
@@ -349,39 +322,22 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
         }
     }
     __syncthreads();
-    if (MODE == 0) {
-        int* g = a.counts + (int64_t)cand * a.nt;
-        for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK)
-            if (cnt[t]) atomicAdd(&g[t], cnt[t]);
-        return;
-    }
+    // block-local exclusive prefix of the tile counters: thread i owns counters [i per_thread, (i + 1) per_thread)
     const int per_thread = (a.nt + PCL_BLOCK - 1) / PCL_BLOCK, t_lo = (int)threadIdx.x * per_thread, t_hi = min(t_lo + per_thread, a.nt);
-    if (MODE == 1) {
-        int* cur = a.cursors + (int64_t)cand * a.nt;
-        for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
-            int c = cnt[t];
-            base[t] = c ? atomicAdd(&cur[t], c) : 0;   // this block's range inside the tile's list
-            cnt[t] = 0;                                // becomes the block-local cursor
-        }
-    } else {
-        // block-local exclusive prefix of the tile counters: thread i owns counters [i per_thread, (i + 1) per_thread)
-        __shared__ int wave_total[PCL_BLOCK / PCL_WAVE];
-        int s = 0;
-        for (int t = t_lo; t < t_hi; t++) s += cnt[t];
-        const int incl = pcl_wave_scan_incl(s);
-        if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
-        __syncthreads();
-        int run = incl - s;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_total[w];
-        for (int t = t_lo; t < t_hi; t++) {
-            const int c = cnt[t];
-            base[t] = run + (int)blockIdx.x * (4 * PCL_BIN_PTS);   // first entry of this (block, tile) run inside the candidate's list area
-            run += c;
-            cnt[t] = 0;
-        }
+    int s = 0;
+    for (int t = t_lo; t < t_hi; t++) s += cnt[t];
+    const int incl = pcl_wave_scan_incl(s);
+    if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - s;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wave_total[w];
+    for (int t = t_lo; t < t_hi; t++) {
+        const int c = cnt[t];
+        base[t] = run + (int)blockIdx.x * (4 * PCL_BIN_PTS);   // first entry of this (block, tile) run inside the candidate's list area
+        run += c;
+        cnt[t] = 0;                                    // becomes the run's cursor
     }
     __syncthreads();
-    const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
     uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -390,68 +346,28 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
         for (int j = 0; j < 4; j++) {
             const int t = tiles[k][j];
             if (t < 0) continue;
-            const int pos = (MODE == 1 ? off[t] : 0) + base[t] + atomicAdd(&cnt[t], 1);
+            const int pos = base[t] + atomicAdd(&cnt[t], 1);
             // the projection travels with the entry: the resolve kernel reads 12 coalesced bytes per entry instead of chasing
-            // slot -> x, y, z and projecting a third time
+            // slot -> x, y, z and projecting again
             list[pos] = pix[k];
             list[a.cap + pos] = dep[k];
             list[2 * a.cap + pos] = (uint32_t)i;
         }
     }
-    if (MODE == 2) {
-        // publish the runs LAST: the atomics' round trips then delay nobody (the counters hold the run lengths again once every entry
-        // has been written)
-        __syncthreads();
-        unsigned long long* st = a.stat + (int64_t)cand * a.nt;
-        uint2* runs = a.runs + (int64_t)cand * a.nt * a.nb;
-        for (int t = t_lo; t < t_hi; t++) {
-            const int c = cnt[t];
-            if (!c) continue;
-            const unsigned long long old = atomicAdd(&st[t], (1ull << 32) | (unsigned long long)c);
-            runs[(int64_t)t * a.nb + (int64_t)(old >> 32)] = make_uint2((uint32_t)base[t], (uint32_t)old);   // (first entry, tile entries before it)
-        }
+    // publish the runs LAST: the atomics' round trips then delay nobody (the counters hold the run lengths again once every entry
+    // has been written)
+    __syncthreads();
+    unsigned long long* st = a.stat + (int64_t)cand * a.nt;
+    uint2* runs = a.runs + (int64_t)cand * a.nt * a.nb;
+    for (int t = t_lo; t < t_hi; t++) {
+        const int c = cnt[t];
+        if (!c) continue;
+        const unsigned long long old = atomicAdd(&st[t], (1ull << 32) | (unsigned long long)c);
+        runs[(int64_t)t * a.nb + (int64_t)(old >> 32)] = make_uint2((uint32_t)base[t], (uint32_t)old);   // (first entry, tile entries before it)
     }
 }
 
-// exclusive scan of the tile counts of one candidate; also zeroes its cursors
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_scan_kernel(PclBinArgs a)
-{
-    __shared__ int part[PCL_BLOCK];
-    const int cand = blockIdx.x;
-    const int* cnt = a.counts + (int64_t)cand * a.nt;
-    int* off = a.offsets + (int64_t)cand * (a.nt + 1);
-    int* cur = a.cursors + (int64_t)cand * a.nt;
-    const int per = (a.nt + PCL_BLOCK - 1) / PCL_BLOCK, lo = threadIdx.x * per, hi = min(lo + per, a.nt);
-    int s = 0;
-    for (int t = lo; t < hi; t++) s += cnt[t];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = 0; k < PCL_BLOCK; k++) { int v = part[k]; part[k] = run; run += v; }
-        off[a.nt] = run;
-    }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int t = lo; t < hi; t++) { off[t] = run; run += cnt[t]; cur[t] = 0; }
-    // Longest first: a far wall seen from the other end of the room puts 40k points into one tile (20x the mean); a heavy
-    // tile that starts late IS the kernel's tail.  Rank by count (ties by index): order[rank] = tile.
-    extern __shared__ int cl[];                        // the counts, for the nt^2 comparisons
-    int* ord = a.order + (int64_t)cand * a.nt;
-    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) cl[t] = cnt[t];
-    __syncthreads();
-    for (int t = threadIdx.x; t < a.nt; t += PCL_BLOCK) {
-        const int c = cl[t];
-        int rank = 0;
-        for (int u = 0; u < a.nt; u++) {
-            const int cu = cl[u];
-            rank += (cu > c || (cu == c && u < t)) ? 1 : 0;
-        }
-        ord[rank] = t;
-    }
-}
-
-// one-pass form: the resolve launch's order for one candidate — tiles by decreasing entry count (ties by index), each with its run count.
+// The resolve launch's order for one candidate — tiles by decreasing entry count (ties by index), each with its run count.
 // A block ranks 64 tiles, each wave against a quarter of the counts (a block per candidate with every thread walking all nt counts was
 // 29 us of LDS latency for 512 tiles, as much as the scan it replaced).
 __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_rank_kernel(PclBinArgs a)
@@ -509,16 +425,8 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // candidate fastest: workgroups are handed out x first, so rank 0 — the heaviest tile — of EVERY candidate starts before
     // any rank-1 tile (tile-major launches started the last candidate's heaviest tile at 94 % of the launch)
     const int cand = blockIdx.x;
-    const bool onepass = a.heads != nullptr;
-    int t, e0, e1, nruns = 0;
-    if (onepass) {
-        const int4 hd = a.heads[(int64_t)cand * a.nt + blockIdx.y];    // heaviest tiles first
-        t = hd.x; nruns = hd.y; e0 = 0; e1 = hd.z;
-    } else {
-        t = a.order[(int64_t)cand * a.nt + blockIdx.y];
-        const int* off = a.offsets + (int64_t)cand * (a.nt + 1);
-        e0 = off[t]; e1 = off[t + 1];
-    }
+    const int4 hd = a.heads[(int64_t)cand * a.nt + blockIdx.y];        // heaviest tiles first
+    const int t = hd.x, nruns = hd.y, total = hd.z;
 #ifdef PCL_BLOCK_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -526,21 +434,20 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     const int drow[9] = {0, 0, -1, -1, -1, 1, 1, 1, 0};   // pass order idx8,7,6,5,4,3,2,1,centre (utils.py:173-198)
     const int dcol[9] = {-1, 1, -1, 0, 1, -1, 0, 1, 0};
     const uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
-    if (e0 == e1) return;                              // nothing projects here (or the tile is outside the scored rows)
-    // One-pass lists: the tile's entries are `nruns` runs (one per bin block that touched the tile) somewhere in the candidate's list
+    if (total == 0) return;                            // nothing projects here (or the tile is outside the scored rows)
+    // The tile's entries are `nruns` runs (one per bin block that touched the tile) somewhere in the candidate's list
     // area.  Entry e of the tile lives at run_first[r] + (e - run_pre[r]) for the last run r with run_pre[r] <= e; the runs' (first
     // entry, entries of the tile before the run) are staged in LDS, every lane finds its run by bisection.  The first PCL_RESOLVE_THREADS
     // runs are requested here, before the tile is initialised (their latency hides behind it); a tile fed by more blocks than that
     // goes through in batches, e0 .. e1 = the entries of one batch.
     __shared__ uint32_t run_first[PCL_RESOLVE_THREADS], run_pre[PCL_RESOLVE_THREADS];
-    const uint2* runs = onepass ? a.runs + ((int64_t)cand * a.nt + t) * a.nb : nullptr;
-    const int total = e1;
+    const uint2* runs = a.runs + ((int64_t)cand * a.nt + t) * a.nb;
     uint2 run0 = make_uint2(0u, 0u);
-    if (onepass && (int)threadIdx.x < nruns) run0 = runs[threadIdx.x];
+    if ((int)threadIdx.x < nruns) run0 = runs[threadIdx.x];
     const int r_org = ty * PCL_TS - 2, c_org = tx * PCL_TS - 2;
     for (int i = threadIdx.x; i < TW * TW; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
     for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
-    if (onepass) { run_first[threadIdx.x] = run0.x; run_pre[threadIdx.x] = run0.y; }
+    run_first[threadIdx.x] = run0.x; run_pre[threadIdx.x] = run0.y;
     __syncthreads();
     // The list is walked in slabs of PCL_RESOLVE_THREADS entries staged through LDS: the loads are coalesced (lane = entry),
     // but the entries of a list are Morton neighbours — 64 consecutive ones land on a handful of pixels, and LDS atomics of
@@ -550,22 +457,16 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // 17.6 us; with the atomics compiled out 13.7, with the tile reads out as well 9.9 — over half of the walk is the list
     // itself arriving from memory (12 B per entry, 2.5 TB/s over the whole launch).
     __shared__ uint32_t slab[3][PCL_RESOLVE_THREADS];
-    const int nbatch = onepass ? (nruns + PCL_RESOLVE_THREADS - 1) / PCL_RESOLVE_THREADS : 1;
+    const int nbatch = (nruns + PCL_RESOLVE_THREADS - 1) / PCL_RESOLVE_THREADS;
     const int j = ((int)threadIdx.x * 17) & (PCL_RESOLVE_THREADS - 1);
   for (int batch = 0; batch < nbatch; batch++) {
-    int nr = 0;
-    if (onepass) {
-        const int r0 = batch * PCL_RESOLVE_THREADS;
-        nr = min(PCL_RESOLVE_THREADS, nruns - r0);
-        if (batch > 0) {                               // (the previous batch's last slab trip ended with a barrier: the tables are free)
-            if ((int)threadIdx.x < nr) { const uint2 r = runs[r0 + (int)threadIdx.x]; run_first[threadIdx.x] = r.x; run_pre[threadIdx.x] = r.y; }
-            __syncthreads();
-        }
-        e0 = (int)run_pre[0];
-        e1 = r0 + nr < nruns ? (int)runs[r0 + nr].y : total;
+    const int r0 = batch * PCL_RESOLVE_THREADS, nr = min(PCL_RESOLVE_THREADS, nruns - r0);
+    if (batch > 0) {                                   // (the previous batch's last slab trip ended with a barrier: the tables are free)
+        if ((int)threadIdx.x < nr) { const uint2 r = runs[r0 + (int)threadIdx.x]; run_first[threadIdx.x] = r.x; run_pre[threadIdx.x] = r.y; }
+        __syncthreads();
     }
+    const int e0 = (int)run_pre[0], e1 = r0 + nr < nruns ? (int)runs[r0 + nr].y : total;
     auto entry_at = [&](int e) -> int64_t {
-        if (!onepass) return (int64_t)e;
         int lo = 0, hi = nr;                           // the last run that starts at or before e
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -661,7 +562,7 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     if (pcl_hist_trace_buf && threadIdx.x == 0) {
         unsigned long long* tb = pcl_hist_trace_buf + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5;
         tb[0] = __builtin_amdgcn_s_memrealtime();
-        tb[1] = (unsigned long long)(e1 - e0);
+        tb[1] = (unsigned long long)total;
         tb[2] = trace_t0;
         tb[3] = trace_t1;
         tb[4] = trace_t2;
@@ -793,7 +694,8 @@ static bool hist_binned_ok(int64_t n, int H, int W)
 }
 
 // bytes of the render area per candidate: the z-buffer of the splat path, or — when n is given — the larger of that and the
-// tile-binned path's bookkeeping + point lists (4 n entries of 12 bytes: the exact worst case, nothing can overflow)
+// tile-binned path's bookkeeping (the run tables: nt n / 256 bytes — 4 % of the lists for a 2048 x 1024 panorama) + point lists (4 n
+// entries of 12 bytes: the exact worst case, nothing can overflow)
 static size_t hist_render_bytes(int64_t n, int H, int W)
 {
     size_t zb = (size_t)H * W * 8;
@@ -801,8 +703,7 @@ static size_t hist_render_bytes(int64_t n, int H, int W)
     const size_t nt = (size_t)((W + PCL_TS - 1) / PCL_TS) * ((H + PCL_TS - 1) / PCL_TS);
     if (!hist_binned_ok(n, H, W)) return zb;       // the launch would take the splat path anyway: no lists to hold
     const size_t nb = (size_t)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS);
-    // bookkeeping + lists + the two-pass form's projection cache + the one-pass form's tile statistics, launch order and run tables
-    size_t binned = 4 * (nt + 1) * sizeof(int) + (size_t)4 * n * 12 + (size_t)n * 8 + nt * (8 + 16 + nb * 8) + 64;
+    size_t binned = nt * (16 + 8 + nb * 8) + (size_t)4 * n * 12;      // launch order, tile statistics, run tables + lists
     return binned > zb ? binned : zb;
 }
 
@@ -880,20 +781,13 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
     if (!force_splat && roomy && hist_binned_ok(n, H, W)) {
         PclBinArgs b;
         b.cloud = cloud; b.n = n; b.stride = stride; b.poses = recs; b.H = H; b.W = W; b.ntx = ntx; b.nt = nt;
-        // layout of the render area: [ncand] x { counts[nt], offsets[nt + 1], cursors[nt], order[nt] }, [ncand] x lists[3][cap]
-        int* ints = (int*)zbuf;
-        b.counts = ints; b.offsets = ints + (int64_t)ncand * nt; b.cursors = b.offsets + (int64_t)ncand * (nt + 1);
-        b.order = b.cursors + (int64_t)ncand * nt;
-        b.lists = (uint32_t*)(ints + (int64_t)ncand * 4 * ((int64_t)nt + 1));
-        b.cap = cap;
-        b.pcache = b.lists + (int64_t)ncand * 3 * cap;
+        // layout of the render area: [ncand] x heads[nt] (16 B), [ncand] x stat[nt] (8 B), [ncand] x runs[nt][nb] (8 B), [ncand] x lists[3][cap]
         b.nb = (int)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS);
-        const bool twopass = pcl_hist_env_int("PCL_BIN_TWOPASS", 0) != 0;      // (A/B and cross-check: count -> scan -> scatter)
-        char* tail = (char*)(b.pcache + (int64_t)ncand * 2 * n);
-        tail += (16 - ((uintptr_t)tail & 15)) & 15;
-        b.heads = twopass ? nullptr : (int4*)tail;
-        b.stat = (unsigned long long*)(tail + (size_t)ncand * nt * sizeof(int4));
-        b.runs = (uint2*)(b.stat + (size_t)ncand * nt);
+        b.heads = (int4*)zbuf;
+        b.stat = (unsigned long long*)(b.heads + (int64_t)ncand * nt);
+        b.runs = (uint2*)(b.stat + (int64_t)ncand * nt);
+        b.lists = (uint32_t*)(b.runs + (int64_t)ncand * nt * b.nb);
+        b.cap = cap;
         // margins of the fast projection's certificate: 1.5e-6 x the image size (three times the error budget in the kernel's comment),
         // at least 1e-3 pixel; PCL_BIN_EXACT=1: the reference formula for every point (A/B, and the cross-check of the certificate)
         const bool exact_env = pcl_hist_env_int("PCL_BIN_EXACT", 0) != 0;
@@ -901,30 +795,19 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.fast_margin_y = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)H);
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
-        // (a failed memset would leave garbage tile counts, which become list offsets: nothing is launched on top of it)
-        me = twopass ? hipMemsetAsync(b.counts, 0, (size_t)ncand * nt * sizeof(int), s) : hipMemsetAsync(b.stat, 0, (size_t)ncand * nt * sizeof(unsigned long long), s);
+        // (a failed memset would leave garbage tile statistics, which become run indices: nothing is launched on top of it)
+        me = hipMemsetAsync(b.stat, 0, (size_t)ncand * nt * sizeof(unsigned long long), s);
         if (me != hipSuccess) return (int)me;
         hipLaunchKernelGGL(pcl_hist_codes_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0, s, cloud, n, stride, codes);
-        dim3 pgrid((unsigned)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS), (unsigned)ncand);
-        const size_t win_bytes = 0;      // (the LDS-window form of the dedup lived here)
-        // pre-dedup pays where pixels hold several points: measured at 1M points on 2048 x 1024 (0.5 points per pixel) resolve 613 ->
-        // 498, scatter 491 -> 437, count 283 -> 355 us per 64 candidates (-7 % for the stage); at 167k points (0.08 per pixel)
-        // nothing is dropped and the compares cost 9 us per 50 candidates — hence the density gate.  PCL_BIN_DEDUP=0 / 1 forces.
+        dim3 pgrid((unsigned)b.nb, (unsigned)ncand);
+        // pre-dedup pays where pixels hold several points: measured (round 4, two-pass form) at 1M points on 2048 x 1024 (0.5 points per
+        // pixel) resolve 613 -> 498, scatter 491 -> 437, count 283 -> 355 us per 64 candidates (-7 % for the stage); at 167k points (0.08
+        // per pixel) nothing is dropped and the compares cost 9 us per 50 candidates — hence the density gate.  PCL_BIN_DEDUP=0 / 1 forces.
         const int dedup_env = pcl_hist_env_int("PCL_BIN_DEDUP", -1);
         const bool dedup = dedup_env >= 0 ? dedup_env != 0 : 4 * n >= (int64_t)H * W;
-        if (!twopass) {
-            if (dedup) hipLaunchKernelGGL((pcl_bin_kernel<2, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
-            else hipLaunchKernelGGL((pcl_bin_kernel<2, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
-            hipLaunchKernelGGL(pcl_bin_rank_kernel, dim3(ncand, (nt + 63) / 64), dim3(PCL_BLOCK), (size_t)(((nt + 3) & ~3) + PCL_BLOCK) * sizeof(int), s, b);
-        } else if (dedup) {
-            hipLaunchKernelGGL((pcl_bin_kernel<0, true>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int) + win_bytes, s, b);
-            hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-            hipLaunchKernelGGL((pcl_bin_kernel<1, true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int) + win_bytes, s, b);
-        } else {
-            hipLaunchKernelGGL((pcl_bin_kernel<0, false>), pgrid, dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-            hipLaunchKernelGGL(pcl_bin_scan_kernel, dim3(ncand), dim3(PCL_BLOCK), (size_t)nt * sizeof(int), s, b);
-            hipLaunchKernelGGL((pcl_bin_kernel<1, false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
-        }
+        if (dedup) hipLaunchKernelGGL((pcl_bin_kernel<true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+        else hipLaunchKernelGGL((pcl_bin_kernel<false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
+        hipLaunchKernelGGL(pcl_bin_rank_kernel, dim3(ncand, (nt + 63) / 64), dim3(PCL_BLOCK), (size_t)(((nt + 3) & ~3) + PCL_BLOCK) * sizeof(int), s, b);
         const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
         const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
         if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, qmask, codes, cpi, nsh, nsw, ghist_c);
