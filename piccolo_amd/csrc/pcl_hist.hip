@@ -233,14 +233,17 @@ __device__ __forceinline__ void pcl_bin_tiles(int row, int col, int H, int W, in
 // PCL_BIN_DEDUP=0 turns it off (A/B).
 #define PCL_BIN_NEIGH 4
 template <int SH>
-__device__ __forceinline__ bool pcl_bin_dominated_by(uint32_t pix, uint32_t dep)
+__device__ __forceinline__ bool pcl_bin_dominated_by(uint32_t npix, uint32_t dep)
 {
-    // row_shr:SH = 0x110 + SH (lane i reads lane i - SH of its row), row_shl:SH = 0x100 + SH; lanes without a source keep `old`
-    const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)pix, 0x110 + SH, 0xf, 0xf, false);
-    const uint32_t da = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x110 + SH, 0xf, 0xf, false);
-    const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)0xfffffffe, (int)pix, 0x100 + SH, 0xf, 0xf, false);
-    const uint32_t db = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x100 + SH, 0xf, 0xf, false);
-    return (int)((pa == pix) & (da < dep)) | (int)((pb == pix) & (db < dep));
+    // row_shr:SH = 0x110 + SH (lane i reads lane i - SH of its row), row_shl:SH = 0x100 + SH, bound_ctrl: lanes without a source read 0.
+    // The pixels travel COMPLEMENTED (npix = ~pix): the 0 of a missing source is then the complement of the "no pixel" marker 0xffffffff,
+    // which equals no live lane's pixel (an `old` operand per DPP read instead cost one v_mov each: 128 of the kernel's ~1300 VALU
+    // instructions per thread).
+    const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)npix, 0x110 + SH, 0xf, 0xf, true);
+    const uint32_t da = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x110 + SH, 0xf, 0xf, true);
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)npix, 0x100 + SH, 0xf, 0xf, true);
+    const uint32_t db = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dep, 0x100 + SH, 0xf, 0xf, true);
+    return (int)((pa == npix) & (da < dep)) | (int)((pb == npix) & (db < dep));
 }
 
 template <bool DEDUP>
@@ -264,6 +267,10 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     uint32_t pix[PER], dep[PER];
     const PclPoseRec* __restrict__ pr = a.poses + cand;
     int pend[PER];
+    // 32-bit offsets through buffer resources (n < 2^28: a plane of the cloud / of the lists is below 4 GB): the 64-bit address of every
+    // load and of three stores per entry was a fifth of the kernel's VALU instructions
+    __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 3 * 4), 0x00020000);
+    const int plane = (int)a.stride * 4;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int64_t i = first + (int64_t)k * PCL_BLOCK;
@@ -271,7 +278,10 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
         dep[k] = 0u;
         pend[k] = -1;
         if (i < a.n) {
-            float qx = a.cloud[i] - pr->t[0], qy = a.cloud[a.stride + i] - pr->t[1], qz = a.cloud[2 * a.stride + i] - pr->t[2];
+            const int voff = (int)i * 4;
+            float qx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cld, voff, 0, 0)) - pr->t[0];
+            float qy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cld, voff, plane, 0)) - pr->t[1];
+            float qz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cld, voff, 2 * plane, 0)) - pr->t[2];
             float px = fmaf(pr->R[2], qz, fmaf(pr->R[1], qy, pr->R[0] * qx));
             float py = fmaf(pr->R[5], qz, fmaf(pr->R[4], qy, pr->R[3] * qx));
             float pz = fmaf(pr->R[8], qz, fmaf(pr->R[7], qy, pr->R[6] * qx));
@@ -303,9 +313,10 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             // (`|`, not `||`: every lane takes part in every DPP read — a short-circuit would switch source lanes off)
-            int dom = (int)pcl_bin_dominated_by<1>(pix[k], dep[k]) | (int)pcl_bin_dominated_by<2>(pix[k], dep[k]);
-            if (PCL_BIN_NEIGH >= 3) dom |= (int)pcl_bin_dominated_by<3>(pix[k], dep[k]);
-            if (PCL_BIN_NEIGH >= 4) dom |= (int)pcl_bin_dominated_by<4>(pix[k], dep[k]);
+            const uint32_t npix = ~pix[k];             // (a lane without a pixel sends 0: it may "match" a missing source — and stays without a pixel)
+            int dom = (int)pcl_bin_dominated_by<1>(npix, dep[k]) | (int)pcl_bin_dominated_by<2>(npix, dep[k]);
+            if (PCL_BIN_NEIGH >= 3) dom |= (int)pcl_bin_dominated_by<3>(npix, dep[k]);
+            if (PCL_BIN_NEIGH >= 4) dom |= (int)pcl_bin_dominated_by<4>(npix, dep[k]);
             if (dom) pix[k] = 0xffffffffu;             // a nearer point owns this pixel (the compares above all saw the originals:
         }                                              // k is a different point set per trip)
     }
@@ -339,19 +350,22 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_bin_kernel(PclBinArgs a)
     }
     __syncthreads();
     uint32_t* list = a.lists + (int64_t)cand * 3 * a.cap;
+    __amdgpu_buffer_rsrc_t l_pix = __builtin_amdgcn_make_buffer_rsrc((void*)list, 0, (int)(a.cap * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t l_dep = __builtin_amdgcn_make_buffer_rsrc((void*)(list + a.cap), 0, (int)(a.cap * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t l_id = __builtin_amdgcn_make_buffer_rsrc((void*)(list + 2 * a.cap), 0, (int)(a.cap * 4), 0x00020000);
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int64_t i = first + (int64_t)k * PCL_BLOCK;
+        const uint32_t i = (uint32_t)(first + (int64_t)k * PCL_BLOCK);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int t = tiles[k][j];
             if (t < 0) continue;
-            const int pos = base[t] + atomicAdd(&cnt[t], 1);
+            const int pos = (base[t] + atomicAdd(&cnt[t], 1)) * 4;
             // the projection travels with the entry: the resolve kernel reads 12 coalesced bytes per entry instead of chasing
             // slot -> x, y, z and projecting again
-            list[pos] = pix[k];
-            list[a.cap + pos] = dep[k];
-            list[2 * a.cap + pos] = (uint32_t)i;
+            __builtin_amdgcn_raw_buffer_store_b32(pix[k], l_pix, pos, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(dep[k], l_dep, pos, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(i, l_id, pos, 0, 0);
         }
     }
     // publish the runs LAST: the atomics' round trips then delay nobody (the counters hold the run lengths again once every entry
