@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 7 /* 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
+#define PCL_ABI_VERSION 8 /* 8: PCL_PANO_U8V / pcl_pano_pack_u8v; 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -77,6 +77,10 @@ const char *pcl_library_hash(void);
  * 1.5 texture accesses per sample on average instead of 2, with the memory of PCL_PANO_U8.  Only the forward-only trim launch takes
  * it (pcl_trim_loss / pcl_trim_loss_images: bound by the texture unit's line rate); pcl_pano_pack_u8p packs it. */
 #define PCL_PANO_U8P 3
+/* PCL_PANO_U8V: RGBA8 in VERTICAL PAIRS — element (x, y) = 8 bytes = texel (x, y), texel (x, y + 1) of the bordered image, H + 2 element
+ * rows of W + 2 elements.  Every 2 x 2 footprint is ONE 16-byte access, for twice the texture bytes of PCL_PANO_U8.  Only the trim
+ * launch takes it (dense clouds, where that launch is bound by texture accesses and VALU issue alike); pcl_pano_pack_u8v packs it. */
+#define PCL_PANO_U8V 4
 int64_t pcl_cloud_stride(int64_t n);
 size_t pcl_cloud_bytes(int64_t n);
 int pcl_cloud_pack(const float *xyz, const float *rgb, const int64_t *order, int64_t n, float *cloud, void *stream);
@@ -91,6 +95,7 @@ size_t pcl_pano_bytes(int H, int W, int pano_format);
 int pcl_pano_pack(const float *img_hwc, int H, int W, float *pano, void *stream);
 int pcl_pano_pack_u8(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
 int pcl_pano_pack_u8p(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
+int pcl_pano_pack_u8v(const float *img_hwc, int H, int W, uint32_t *pano, int *not_exact, void *stream);
 int pcl_pano_pack_f16(const float *img_hwc, int H, int W, void *pano, int *not_exact, void *stream);
 
 /* ---- sampling loss (+ gradient) ----------------------------------------------------------------------------

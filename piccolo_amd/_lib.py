@@ -11,11 +11,11 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 16
 GD_SEQUENTIAL, GD_BATCH = 0, 1
-PANO_F32, PANO_U8, PANO_F16, PANO_U8P = 0, 1, 2, 3
+PANO_F32, PANO_U8, PANO_F16, PANO_U8P, PANO_U8V = 0, 1, 2, 3, 4
 
 
 class GdHyper(_c.Structure):
@@ -40,6 +40,7 @@ SIGNATURES = {
     "pcl_cloud_order": (_int, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "pcl_pano_pack_u8": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_pano_pack_u8p": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
+    "pcl_pano_pack_u8v": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_pano_pack_f16": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
     "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),

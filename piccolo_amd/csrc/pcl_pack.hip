@@ -32,6 +32,7 @@ extern "C" size_t pcl_pano_bytes(int H, int W, int pano_format)
 {
     if (H <= 0 || W <= 0) return 0;
     if (pano_format == PCL_PANO_U8P) return (size_t)((H + 3) >> 1) * (size_t)(W + 2) * 8;       // element rows of row PAIRS
+    if (pano_format == PCL_PANO_U8V) return (size_t)(H + 2) * (size_t)(W + 2) * 8;              // every texel with the one below it
     if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16) return 0;
     return (size_t)(H + 2) * (size_t)(W + 2) * (size_t)pcl_texel_bytes(pano_format);
 }
@@ -260,6 +261,43 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8p_kernel(const floa
         if (bad) *not_exact = 1;
     }
     pano[((int64_t)(yp >> 1) * Wp + xp) * 2 + (yp & 1)] = v;
+}
+
+// RGBA8 in vertical pairs (PCL_PANO_U8V): element (xp, yp) = texel (xp, yp), texel (xp, yp + 1) of the bordered image.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_pano_pack_u8v_kernel(const float* __restrict__ img, int H, int W,
+                                                                      pcl_i2* __restrict__ pano, int* __restrict__ not_exact)
+{
+    const int Wp = W + 2, Hp = H + 2;
+    int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (i >= (int64_t)Wp * Hp) return;
+    const int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+    uint32_t v[2] = {0u, 0u};
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const int y = yp + d;
+        if (y >= 1 && y <= H && xp >= 1 && xp <= W) {
+            const float* s = img + ((int64_t)(y - 1) * W + (xp - 1)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float f = s[c], k = rintf(f * 255.f);
+                bad = bad || !(k >= 0.f && k <= 255.f) || __fdiv_rn(k, 255.f) != f;
+                v[d] |= ((uint32_t)k & 255u) << (8 * c);
+            }
+        }
+    }
+    if (bad) *not_exact = 1;
+    pano[i] = (pcl_i2){(int)v[0], (int)v[1]};
+}
+
+extern "C" int pcl_pano_pack_u8v(const float* img_hwc, int H, int W, uint32_t* pano, int* not_exact, void* stream)
+{
+    if (!img_hwc || !pano || !not_exact || H <= 0 || W <= 0) return PCL_EINVAL;
+    int64_t total = (int64_t)(H + 2) * (W + 2);
+    hipLaunchKernelGGL(pcl_pano_pack_u8v_kernel, dim3((unsigned)((total + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0,
+                       (hipStream_t)stream, img_hwc, H, W, (pcl_i2*)pano, not_exact);
+    PCL_LAUNCH_CHECK();
+    return 0;
 }
 
 // half4 texels holding the levels 0..255 as fp16 (exact), for the same k/255 images as RGBA8.

@@ -230,6 +230,20 @@ __device__ __forceinline__ PclTaps<PCL_PANO_U8> pcl_taps_u8_of(const PclTaps<PCL
     t.bot = (pcl_i2){odd ? p.b.x : p.a.y, odd ? p.b.z : p.a.w};
     return t;
 }
+// PCL_PANO_U8V: every texel stored with the one below it — the footprint is one 16-byte access on any row, for twice the texture
+template <> struct PclTaps<PCL_PANO_U8V> { pcl_i4 a; };
+template <>
+__device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8V>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool, PclTaps<PCL_PANO_U8V>& o)
+{
+    o.a = __builtin_amdgcn_raw_buffer_load_b128(tex, (row + x0) * 8, 0, 0);          // elements (x0, y0), (x0 + 1, y0)
+}
+__device__ __forceinline__ PclTaps<PCL_PANO_U8> pcl_taps_u8_of(const PclTaps<PCL_PANO_U8V>& p, bool)
+{
+    PclTaps<PCL_PANO_U8> t;
+    t.top = (pcl_i2){p.a.x, p.a.z};
+    t.bot = (pcl_i2){p.a.y, p.a.w};
+    return t;
+}
 template <>
 __device__ __forceinline__ void pcl_issue_taps_row<PCL_PANO_U8>(__amdgpu_buffer_rsrc_t tex, int row, int x0, int Wp, bool, PclTaps<PCL_PANO_U8>& o)
 {
@@ -290,6 +304,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
 
     __amdgpu_buffer_rsrc_t tex = FMT == PCL_PANO_U8P
         ? __builtin_amdgcn_make_buffer_rsrc((void*)a.pano[image], 0, (int)((size_t)((a.dims.H + 3) >> 1) * (size_t)a.dims.Wp * 8), 0x00020000)
+        : FMT == PCL_PANO_U8V ? pcl_tex_rsrc(a.pano[image], a.dims.H, a.dims.W, 8)
         : pcl_tex_rsrc(a.pano[image], a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
     __amdgpu_buffer_rsrc_t cld = __builtin_amdgcn_make_buffer_rsrc((void*)a.cloud, 0, (int)(a.stride * 6 * 4), 0x00020000);
     const int plane = (int)a.stride * 4;
@@ -386,7 +401,7 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
 #pragma unroll
         for (int yy = 0; yy < PCL_TRIM_Y; yy++) {
             if (yy >= ny) break;
-            if constexpr (FMT == PCL_PANO_U8P) {
+            if constexpr (FMT == PCL_PANO_U8P || FMT == PCL_PANO_U8V) {
                 PclProj<PCL_PANO_U8> q;
                 q.px = q.py = q.pz = F2(0.f);
                 q.fx = pj[yy].fx; q.fy = pj[yy].fy;
@@ -469,8 +484,11 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
     for (int i = 0; i < nimages; i++)
         if (!panos_host[i]) return PCL_EINVAL;
     if (n <= 0 || n > PCL_MAX_POINTS || K <= 0 || R <= 0 || ngroups <= 0 || ngroups > R || H <= 0 || W <= 0) return PCL_EINVAL;
-    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16 && pano_format != PCL_PANO_U8P) return PCL_EINVAL;
-    if ((int64_t)(H + 3) * (W + 2) * (pano_format == PCL_PANO_U8P ? 4 : pcl_texel_bytes(pano_format)) >= ((int64_t)1 << 31)) return PCL_EINVAL;
+    if (pano_format != PCL_PANO_F32 && pano_format != PCL_PANO_U8 && pano_format != PCL_PANO_F16 && pano_format != PCL_PANO_U8P &&
+        pano_format != PCL_PANO_U8V)
+        return PCL_EINVAL;
+    if ((int64_t)(H + 3) * (W + 2) * (pano_format == PCL_PANO_U8P ? 4 : pano_format == PCL_PANO_U8V ? 8 : pcl_texel_bytes(pano_format)) >= ((int64_t)1 << 31))
+        return PCL_EINVAL;
     if ((int64_t)ngroups * K * nimages > (1 << 24)) return PCL_EINVAL;
     if (workspace_bytes < trim_workspace_bytes(n, K, ngroups, nimages)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -495,13 +513,14 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
         const char* xe = getenv("PCL_TRIM_XCD_IMAGES");
         a.xcd_images = nimages % 8 == 0 && (xe ? atoi(xe) != 0 : true) ? 1 : 0;
     }
-    a.dims = pcl_make_dims(H, W, pano_format == PCL_PANO_U8P ? PCL_PANO_U8 : pano_format);       // (the same levels, the same constants)
+    a.dims = pcl_make_dims(H, W, pano_format == PCL_PANO_U8P || pano_format == PCL_PANO_U8V ? PCL_PANO_U8 : pano_format);       // (the same levels, the same constants)
     a.poses = recs; a.hdr = hdr; a.groups = grs; a.K = K; a.nslots = nslots; a.partials = partials;
     // the chunks of the SINGLE-image launch, whatever the number of images: per-image tables keep that launch's bits
     pcl_plan_for_groups(n, nslots, &a.nchunks, &a.seg_len, &a.steps_base, &a.steps_rem);
     const int64_t nblk = (int64_t)a.nchunks * nslots * nimages;
     if (nblk > 0x7fffffffll) return PCL_EINVAL;
     if (pano_format == PCL_PANO_U8P) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8P>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
+    else if (pano_format == PCL_PANO_U8V) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8V>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_F16) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F16>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_F32>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);

@@ -38,7 +38,7 @@ strict_reference_asserts = True
 # cloud, quantile box or translation grid (a dataset loop touches 4 cloud-side entries per room and 2 per image).
 # An entry is keyed by the identity of the tensors it was made from (address, shape, in-place version) and holds weak
 # references to them: a hit needs the very same live tensor, and entries whose tensors died are purged.
-_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 16, "pano_u8p": 16, "gd": 6, "trimgroups": 4}
+_CAPACITY = {"cloud": 2, "order": 2, "box": 8, "grid": 4, "pano": 16, "pano_u8": 16, "pano_u8p": 16, "pano_u8v": 16, "gd": 6, "trimgroups": 4}
 
 
 class _PackCache:
@@ -117,7 +117,8 @@ def packed_pano(img, many_poses=False, n_points=None):
     evaluates hundreds of candidate poses all over the room (`many_poses`, trim_input_loss: with 1800 poses the fp16 texture
     thrashes L2, 8.7 vs 5.3 ms per launch at cfg-2 size) or when the cloud to be refined is sparse against the panorama
     (`n_points`: ops.refine_texels); fp16-level texels otherwise (the refinement's nearby poses on a dense cloud run 5 % faster on
-    them).  The trim launch of a SPARSE cloud takes its own layout ('u8p', rows interleaved in pairs, cache 'pano_u8p'), so at the
+    them).  The trim launch of a SPARSE cloud takes its own layout ('u8p', rows interleaved in pairs, cache 'pano_u8p'; a DENSE one
+    'u8v', vertical pairs), so at the
     shipped 167k-point shape an image whose initialisation and refinement use the same tensor is packed twice (8 MB each, two
     caches): the two stages share a packing only for dense clouds' trim ('u8') and a sparse cloud's refinement ('u8').  Images that
     are not k/255 get float4 texels either way."""
@@ -126,9 +127,10 @@ def packed_pano(img, many_poses=False, n_points=None):
         rgba8 = False
     if not rgba8:
         return _cached("pano", (img,), lambda: ops.Pano(img))
-    # the trim launch of a sparse cloud takes the rows interleaved in pairs (ops.trim_texels); nothing else reads that layout
-    fmt = "u8p" if many_poses and n_points is not None and ops.trim_texels(n_points, img.shape[0], img.shape[1]) == "u8p" else "u8"
-    if os.environ.get("PCL_TRIM_FMT") in ("u8", "u8p") and many_poses:            # experiments
+    # the trim launch picks its own layout by point density (ops.trim_texels: rows interleaved in pairs / plain rows / vertical pairs);
+    # nothing else reads the paired layouts
+    fmt = ops.trim_texels(n_points, img.shape[0], img.shape[1]) if many_poses and n_points is not None else "u8"
+    if os.environ.get("PCL_TRIM_FMT") in ("u8", "u8p", "u8v") and many_poses:     # experiments
         fmt = os.environ["PCL_TRIM_FMT"]
 
     def make():

@@ -88,7 +88,8 @@ class Pano:
     exactness test is one kernel and one 4-byte D2H read per image, outside the GD loop."""
 
     _PACK = {"f16": ("pcl_pano_pack_f16", _lib.PANO_F16), "u8": ("pcl_pano_pack_u8", _lib.PANO_U8),
-             "u8p": ("pcl_pano_pack_u8p", _lib.PANO_U8P)}         # u8p: rows interleaved in pairs, for the trim launch only
+             "u8p": ("pcl_pano_pack_u8p", _lib.PANO_U8P),         # u8p: rows interleaved in pairs, u8v: vertical pairs — trim launch only
+             "u8v": ("pcl_pano_pack_u8v", _lib.PANO_U8V)}
 
     def __init__(self, img, fmt="auto"):
         lib = _lib.load()
@@ -98,7 +99,7 @@ class Pano:
             raise ValueError("img must be (H, W, 3)")
         self.H, self.W = int(img.shape[0]), int(img.shape[1])
         self.fmt = None
-        if fmt not in ("auto", "f16", "u8", "u8p", "f32"):
+        if fmt not in ("auto", "f16", "u8", "u8p", "u8v", "f32"):
             raise ValueError("unknown texel format %r" % (fmt,))
         prefer = "f16"
         if fmt == "auto":                                     # experiments: PCL_PANO_FMT = what "auto" tries first
@@ -135,11 +136,16 @@ def refine_texels(n, H, W):
 
 
 def trim_texels(n, H, W):
-    """Level-texel format ("u8" | "u8p") for the TRIM launch of an n-point cloud against an H x W panorama: rows interleaved in pairs
-    (1.5 texture accesses per sample instead of 2, same bytes) where the launch is bound by the texture unit's line rate — measured
-    167k points 1.05 -> 0.87 ms, 400k 1.77 -> 1.53 ms per 1800-pose launch on 2048 x 1024, bit-identical tables — and plain rows
-    where it is VALU-bound (1M points: 3.3 ms either way, the four selects per sample cost what the saved accesses buy)."""
-    return "u8p" if 3 * int(n) < int(H) * int(W) else "u8"
+    """Level-texel layout ("u8p" | "u8" | "u8v") for the TRIM launch of an n-point cloud against an H x W panorama, by point density.
+    Sparse (fewer than one point per three pixels): rows interleaved in pairs — 1.5 texture accesses per sample instead of 2, same
+    bytes; the launch is bound by the texture unit's line rate there (167k points 1.05 -> 0.87 ms, 400k 1.77 -> 1.53 ms per 1800-pose
+    launch on 2048 x 1024).  Dense (from 5 points per 12 pixels): vertical pairs — ONE access per sample for twice the texture; it
+    loses where the texture has to stay in the L2s (167k 1.02 -> 1.24 ms, 400k 1.72 -> 1.94) and wins where accesses and VALU issue
+    bind together (850k 2.84 -> 2.80, 1M 3.20 -> 3.12, 2M 5.79 -> 5.51 ms; u8p there: 3.34 / 6.44, its four selects per sample cost
+    more than its saved accesses buy).  Plain rows in between.  The three layouts give the same table bit for bit
+    (tools/trim_u8p.py, tests/test_hip_parity.py::test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle)."""
+    n, px = int(n), int(H) * int(W)
+    return "u8p" if 3 * n < px else "u8v" if 12 * n >= 5 * px else "u8"
 
 
 def _known_levels(img):

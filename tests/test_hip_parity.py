@@ -269,18 +269,22 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
     # RGBA8 with the rows interleaved in pairs (PCL_PANO_U8P, the trim launch's format for sparse clouds): the same texels through
     # one 16-byte access (even rows) or two (odd rows) — tables and counts bit-identical to row-major RGBA8, for every grid shape,
     # also on a panorama with an odd number of rows (a last half pair) and for several images per launch
+    # (and PCL_PANO_U8V, the format for dense clouds: every texel stored with the one below it, one 16-byte access per footprint)
     for name, rot, tr, _ in cases[:4]:
         groups = ops.TrimGroups(T(rot))
         t8, c8 = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(tr), groups, return_count=True)
-        tp, cp = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8p"), T(tr), groups, return_count=True)
-        assert torch.equal(torch.nan_to_num(t8, nan=-1.0), torch.nan_to_num(tp, nan=-1.0)) and torch.equal(c8, cp), name
+        for paired in ("u8p", "u8v"):
+            tp, cp = ops.trim_loss_table(cloud, ops.Pano(img, fmt=paired), T(tr), groups, return_count=True)
+            assert torch.equal(torch.nan_to_num(t8, nan=-1.0), torch.nan_to_num(tp, nan=-1.0)) and torch.equal(c8, cp), (name, paired)
     img_odd = img[:-1].contiguous()                       # 127 rows
     groups = ops.TrimGroups(T(stanford))
     t8 = ops.trim_loss_table(cloud, ops.Pano(img_odd, fmt="u8"), T(trans), groups)
-    tp = ops.trim_loss_tables(cloud, [ops.Pano(img_odd, fmt="u8p"), ops.Pano(img_odd, fmt="u8p")], T(trans), groups)
-    assert torch.equal(t8, tp[0]) and torch.equal(t8, tp[1])
-    with pytest.raises(Exception):                         # nothing but the trim launch reads that layout
-        ops.sampling_loss(cloud, ops.Pano(img, fmt="u8p"), T(trans[:2]), T(stanford[:2]))
+    for paired in ("u8p", "u8v"):
+        tp = ops.trim_loss_tables(cloud, [ops.Pano(img_odd, fmt=paired), ops.Pano(img_odd, fmt=paired)], T(trans), groups)
+        assert torch.equal(t8, tp[0]) and torch.equal(t8, tp[1]), paired
+        with pytest.raises(Exception):                     # nothing but the trim launch reads these layouts
+            ops.sampling_loss(cloud, ops.Pano(img, fmt=paired), T(trans[:2]), T(stanford[:2]))
+    assert [ops.trim_texels(n_, 1024, 2048) for n_ in (166_667, 700_000, 1_000_000)] == ["u8p", "u8", "u8v"]
     # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once
     groups = ops.TrimGroups(T(stanford))
     want = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()

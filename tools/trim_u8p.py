@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Trim launch with row-major RGBA8 texels vs rows interleaved in pairs (PCL_PANO_U8P): tables must agree bit for bit; ms per launch.
+"""Trim launch with row-major RGBA8 texels vs rows interleaved in pairs (PCL_PANO_U8P) vs vertical pairs (PCL_PANO_U8V): tables must agree
+bit for bit; ms per launch.
    python tools/trim_u8p.py [n_points ...]"""
 import os, sys, time
 import numpy as np, torch
@@ -17,7 +18,7 @@ for n in [int(a) for a in sys.argv[1:]] or [166_667, 1_000_000]:
     trans = utils.generate_trans_points(X, bench.STANFORD_INIT, device=dev)
     groups, cloud = ops.TrimGroups(rot), ops.Cloud(X, C)
     out = {}
-    for fmt in ("u8", "u8p", "u8", "u8p"):
+    for fmt in ("u8", "u8p", "u8v", "u8", "u8p", "u8v"):
         pano = ops.Pano(img, fmt=fmt)
         t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize()
         ts = []
@@ -25,6 +26,5 @@ for n in [int(a) for a in sys.argv[1:]] or [166_667, 1_000_000]:
             t0 = time.perf_counter(); t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         out.setdefault(fmt, []).append(float(np.median(ts)))
         out[fmt + "_table"] = t
-    print("n %d: u8 %s ms | u8p %s ms | tables equal: %s (NaN-aware), max abs diff %.3e" % (
-        n, out["u8"], out["u8p"], bool(torch.equal(torch.nan_to_num(out["u8_table"], nan=-1.0), torch.nan_to_num(out["u8p_table"], nan=-1.0))),
-        float((out["u8_table"] - out["u8p_table"]).abs().nan_to_num().max())))
+    same = lambda a, b: bool(torch.equal(torch.nan_to_num(out[a + "_table"], nan=-1.0), torch.nan_to_num(out[b + "_table"], nan=-1.0)))
+    print("n %d: u8 %s ms | u8p %s ms | u8v %s ms | tables equal (NaN-aware): u8p %s, u8v %s" % (n, out["u8"], out["u8p"], out["u8v"], same("u8", "u8p"), same("u8", "u8v")))
