@@ -458,6 +458,25 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     const uint2* runs = a.runs + ((int64_t)cand * a.nt + t) * a.nb;
     uint2 run0 = make_uint2(0u, 0u);
     if ((int)threadIdx.x < nruns) run0 = runs[threadIdx.x];
+    // ... and so are this thread's query-mask bytes: which of its pixels can count at all (inside the image, in a scored block row, query
+    // pixel not black) does not depend on the render — one bit per pixel, loaded while the list is walked instead of in front of the
+    // dependent colour gather of the histogram phase
+    const int bh = a.H / nsh, bw = a.W / nsw, nblk = (nsh - 2) * nsw;
+    const int h_lo = (ty * PCL_TS) / bh, w_lo = (tx * PCL_TS) / bw;       // first histogram block row / column of this tile
+    const bool big_blocks = bh >= PCL_TS && bw >= PCL_TS;
+    constexpr int NPIX = PCL_TS * PCL_TS / PCL_RESOLVE_THREADS;
+    uint8_t qbyte[NPIX];
+#pragma unroll
+    for (int k = 0; k < NPIX; k++) {
+        const int i = (int)threadIdx.x + k * PCL_RESOLVE_THREADS;
+        const int r = ty * PCL_TS + (i >> PCL_TS_SHIFT), c = tx * PCL_TS + (i & (PCL_TS - 1));
+        // (blocks at least a tile wide and high — every shipped config — span at most two block rows / columns per tile: a compare
+        //  instead of two integer divisions per pixel)
+        const int h = big_blocks ? h_lo + (r >= (h_lo + 1) * bh ? 1 : 0) : r / bh;
+        const int w = big_blocks ? w_lo + (c >= (w_lo + 1) * bw ? 1 : 0) : c / bw;
+        const bool scored = r < a.H && c < a.W && h >= 1 && h <= nsh - 2 && w < nsw;      // only the middle block rows (utils.py:556)
+        qbyte[k] = scored ? qm[(int64_t)r * a.W + c] : (uint8_t)0;                        // 0: query pixel black (mask written with the query histograms)
+    }
     const int r_org = ty * PCL_TS - 2, c_org = tx * PCL_TS - 2;
     for (int i = threadIdx.x; i < TW * TW; i += PCL_RESOLVE_THREADS) tile[i] = ~0ull;
     for (int i = threadIdx.x; i < 4 * PCL_HBINS; i += PCL_RESOLVE_THREADS) (&hist[0][0])[i] = 0u;
@@ -537,21 +556,16 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // stage) — 0.434 -> 0.460 ms for the stage at 167k x 50, 1.35 -> 1.41 at 1M x 64; wave-voted histogram adds (one LDS atomic
     // per distinct colour code of a wave instead of 64 on one address) — 0.433 -> 0.490 / 1.34 -> 1.40.  Neither the load latency
     // nor the same-address atomics are what the loop waits for.
-    const int bh = a.H / nsh, bw = a.W / nsw, nblk = (nsh - 2) * nsw;
-    const int h_lo = (ty * PCL_TS) / bh, w_lo = (tx * PCL_TS) / bw;       // first histogram block row / column of this tile
     unsigned int* g = ghist + (int64_t)cand * nblk * PCL_HBINS;
-    const bool big_blocks = bh >= PCL_TS && bw >= PCL_TS;
-    for (int i = threadIdx.x; i < PCL_TS * PCL_TS; i += PCL_RESOLVE_THREADS) {
+#pragma unroll
+    for (int kk = 0; kk < NPIX; kk++) {
+        if (!qbyte[kk]) continue;
+        const int i = (int)threadIdx.x + kk * PCL_RESOLVE_THREADS;
         const unsigned long long k = tile[((i >> PCL_TS_SHIFT) + 2) * TW + (i & (PCL_TS - 1)) + 2];
+        if (k == ~0ull) continue;
         const int r = ty * PCL_TS + (i >> PCL_TS_SHIFT), c = tx * PCL_TS + (i & (PCL_TS - 1));
-        if (k == ~0ull || r >= a.H || c >= a.W) continue;
-        // (blocks at least a tile wide and high — every shipped config — span at most two block rows / columns per tile: a compare
-        //  instead of two integer divisions per pixel)
         const int h = big_blocks ? h_lo + (r >= (h_lo + 1) * bh ? 1 : 0) : r / bh;
         const int w = big_blocks ? w_lo + (c >= (w_lo + 1) * bw ? 1 : 0) : c / bw;
-        if (h < 1 || h > nsh - 2 || w >= nsw) continue;                  // only the middle block rows (utils.py:556)
-        const int64_t pix = (int64_t)r * a.W + c;
-        if (!qm[pix]) continue;                                          // query pixel black (byte mask written with the query histograms)
         const int64_t j = (int64_t)(0x1fffffffu - (uint32_t)(k & 0x1fffffffull));
         const int code = (int)codes[j];                                  // the winner's 8 x 8 x 8 colour code (pcl_hist_codes_kernel)
         if (code == 0xffff) continue;                                    // its colour is exactly black
