@@ -206,7 +206,8 @@ __device__ __forceinline__ void pcl_loss_body(const PclLossArgs& a, const PclFus
                 tg = pcl_tex_rsrc(pp, a.dims.H, a.dims.W, pcl_texel_bytes(FMT));
             }
             PclProj<FMT> pj;
-            const int zoff = VIS == 2 ? (pose0 + g) * (a.dgrid.last + 1) * 4 : 0;        // this pose's z-buffer (scalar offset)
+            // this pose's z-buffer (scalar offset: 32 unsigned bits, B z-buffers together stay below 4 GiB — pcl_launch_zbuffers checks)
+            const int zoff = VIS == 2 ? (int)((unsigned)(pose0 + g) * (unsigned)(a.dgrid.last + 1) * 4u) : 0;
 #ifndef PCL_NO_ROTATE_PAIR
             if constexpr (G == 2) {
                 pj.px = rot_p[g][0]; pj.py = rot_p[g][1]; pj.pz = rot_p[g][2];
