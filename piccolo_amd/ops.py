@@ -321,7 +321,8 @@ SELECT_MAX_KEEP = 1024      # pcl_select_poses: winners per problem (include/pic
 def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
     `cloud` is a packed Cloud.  Candidates are processed `batch` at a time.  Workspace per candidate: the point lists of the
-    tile-binned render (56 bytes per point in the worst case — 48 of lists, 8 of projection cache: 3.6 GB for 64 candidates at 1M points; HBM is there to be used),
+    tile-binned render (48 bytes per point in the worst case, plus the tiles' run tables — 2 bytes per point for a 2048 x 1024 panorama: 3.2 GB for 64
+    candidates at 1M points; HBM is there to be used),
     or, where that path does not apply (more than 4096 image tiles, ...) or does not fit, H * W * 8 bytes for the z-buffer of the
     splat path.  If the allocation fails the batch is halved, and the last resort is the splat path's small workspace.
     return_parts: (scores, inter, nproj, nimg)."""

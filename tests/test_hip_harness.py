@@ -756,6 +756,34 @@ def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
         img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W))).cpu().numpy()
         tr, ro = synth.start_poses(t_gt, ypr_gt, 1 if n == 5_000 else 9, seed=90, sigma_t=0.5, sigma_r=0.4)
         cases.append((img, xyz, rgb, tr, ro, nh, nw))
+    # One tile fed by more bin blocks than the resolve workgroup has threads (its run table goes through in batches): 2.3M points — 1124
+    # blocks of 2048 — in a sheet that the first candidate, the sheet's own camera, sees in the middle of ONE 64 x 64 tile of a 256 x 128
+    # panorama (the other candidates cut it across tiles), on top of a room.
+    H, W, n_blob = 128, 256, 2_300_000
+    rng = np.random.default_rng(7)
+    t_gt, ypr_gt = synth.gt_pose(91)
+    for _ in range(200):
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        r0, c0 = oracle.pano_pixels((5.0 * d)[None].astype(np.float32), (H, W))
+        if 44 <= int(r0[0]) <= 52 and 12 <= int(c0[0]) % 64 <= 52:          # a scored block row (32 .. 95), mid-tile
+            break
+    else:
+        raise AssertionError("no direction found")
+    e1 = np.cross(d, [0.0, 0.0, 1.0]); e1 /= np.linalg.norm(e1); e2 = np.cross(d, e1)
+    # (a SHEET facing the camera, 20 x 20 pixels: its ~400 winners are spread over all of the tile's runs, the late ones included)
+    cam_blob = (5.0 * d)[None] + rng.uniform(-1.2, 1.2, size=(n_blob, 1)) * e1[None] + rng.uniform(-1.2, 1.2, size=(n_blob, 1)) * e2[None] \
+        + rng.normal(0, 0.002, size=(n_blob, 1)) * d[None]
+    Rgt = synth.rot_from_ypr_np(ypr_gt.astype(np.float64))
+    world_blob = (cam_blob @ Rgt + t_gt[None]).astype(np.float32)            # x = R^T p + t   (p = R (x - t))
+    room_xyz, room_rgb = synth.box_room(50_000, 91)
+    xyz = np.concatenate([room_xyz, world_blob]).astype(np.float32)
+    rgb = np.concatenate([room_rgb, rng.integers(0, 256, size=(n_blob, 3)).astype(np.float32) / 255.0]).astype(np.float32)
+    X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
+    img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(t_gt), torch.from_numpy(ypr_gt)), C, (H, W))).cpu().numpy()
+    tr, ro = synth.start_poses(t_gt, ypr_gt, 3, seed=91, sigma_t=0.05, sigma_r=0.05)
+    tr[0], ro[0] = t_gt, ypr_gt
+    cases.append((img, xyz, rgb, tr, ro, 4, 4))
+    del X, C
     dev = torch.device("cuda")
     try:
         for img, xyz, rgb, tr, ro, nh, nw in cases:
