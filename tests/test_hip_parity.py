@@ -422,7 +422,9 @@ def test_device_optimiser_teacher_forced_all_iterations(ops, parity, tag):
     iterations by the reference's OWN recorded loss_list and autograd gradients (G5: omniloc.py:253-258 wrapped by the golden
     generator), one pcl_gd_step_from_grads per iteration: the pose every forward sees and the leaf Adam updates within 1e-6 of the
     reference's at EVERY step, lr / num_bad_epochs / best exactly the reference's after every scheduler step.  A wrong beta2_pow at
-    step 50 fails here (the free-running tests could not see it).  bat1 / bat2: the start outside the clamp box."""
+    step 50 fails here (the free-running tests could not see it) — checked once against a build whose running product beta2 ** step
+    takes 0.9995 instead of 0.999 from step 41 on: seq0_, seq1_ and bat_ fail, everything else in the suite passes.  bat1 / bat2:
+    the start outside the clamp box."""
     g = load_golden("g5_trajectories.npz")
     cfg = Cfg(**json.loads(str(g["cfg"])))
     batch = tag.startswith("bat")
