@@ -238,6 +238,12 @@ class Ranks:
         # (PCL_DIST_BACKEND=gloo lets several ranks share one GPU: used by the test-suite to run the N > 1 code path end to
         #  end on a single-GPU box; the driver's multi-GPU runs use the default, RCCL, one GPU per rank)
         self.backend = os.environ.get("PCL_DIST_BACKEND", "nccl")
+        # dmabuf IPC for RCCL / tensor sharing between the ranks' processes (the pool's driver supports nothing else): the HSA runtime
+        # reads this when the process first touches the GPU, so it is set BEFORE torch.cuda.set_device below — setting it next to
+        # init_process_group, as rounds 1-4 did, only worked because the boxes export it already
+        if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:                 # (experiments: what happens without dmabuf IPC)
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         self.n_dev = torch.cuda.device_count()
         if self.n_dev < 1:
             raise SystemExit("bench.py needs an MI355X: torch.cuda.device_count() == 0")
@@ -255,9 +261,6 @@ class Ranks:
             os.environ.setdefault("MASTER_PORT", "29531")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:             # (experiments: what happens without dmabuf IPC)
-                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             # An explicit, SHORT rendezvous / collective timeout: a rank that cannot reach the others must end the job with a reason
             # inside the driver's own time limit, not hang in it (torch's default is 10 minutes for nccl, 30 for gloo).
             self.timeout_s = float(os.environ.get("PCL_DIST_TIMEOUT_S", "180"))
