@@ -136,16 +136,26 @@ def refine_texels(n, H, W):
 
 
 def trim_texels(n, H, W):
-    """Level-texel layout ("u8p" | "u8" | "u8v") for the TRIM launch of an n-point cloud against an H x W panorama, by point density.
-    Sparse (fewer than one point per three pixels): rows interleaved in pairs — 1.5 texture accesses per sample instead of 2, same
-    bytes; the launch is bound by the texture unit's line rate there (167k points 1.05 -> 0.87 ms, 400k 1.77 -> 1.53 ms per 1800-pose
-    launch on 2048 x 1024).  Dense (from 5 points per 12 pixels): vertical pairs — ONE access per sample for twice the texture; it
-    loses where the texture has to stay in the L2s (167k 1.02 -> 1.24 ms, 400k 1.72 -> 1.94) and wins where accesses and VALU issue
-    bind together (850k 2.84 -> 2.80, 1M 3.20 -> 3.12, 2M 5.79 -> 5.51 ms; u8p there: 3.34 / 6.44, its four selects per sample cost
-    more than its saved accesses buy).  Plain rows in between.  The three layouts give the same table bit for bit
-    (tools/trim_u8p.py, tests/test_hip_parity.py::test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle)."""
+    """Level-texel layout ("u8p" | "u8" | "u8v") for the TRIM launch of an n-point cloud against an H x W panorama.  Three layouts of the
+    same RGBA8 texels, bit-identical tables (tools/trim_u8p.py, tests/test_hip_parity.py::test_trim_loss_table_yaw_shared_vs_generic_
+    kernel_and_oracle): plain rows `u8` (two 8-byte accesses per 2 x 2 footprint), rows interleaved in pairs `u8p` (1.5 accesses, same
+    bytes, four selects per sample), vertical pairs `u8v` (ONE access, twice the texture).  Which one is fastest depends on what the
+    launch is bound by — texture lines (sparse clouds), L2 residency of the texture under hundreds of concurrent views (large
+    panoramas), VALU issue (dense clouds) — measured per 1800-pose launch, ms (u8 / u8p / u8v):
+        1024 x  512, u8v = 4 MB : 100k points 0.51 / 0.45 / 0.40, 250k 0.84 / 0.87 / 0.73, 500k 1.47 / 1.62 / 1.35    -> u8v always
+        2048 x 1024, u8v = 17 MB: 167k 1.02 / 0.85 / 1.24, 400k 1.72 / 1.51 / 1.94, 700k 2.5 / 2.5 / 2.5, 850k 2.84 / 2.88 / 2.80,
+                                  1M 3.20 / 3.34 / 3.12, 2M 5.79 / 6.44 / 5.51            -> u8p below 1/3 point per pixel, u8v from 5/12
+        4096 x 2048, u8v = 67 MB: 3M 14.1 / 10.3 / 17.0, 6M 20.6 / 19.6 / 25.0, 8M 25.3 / 25.9 / 29.5, 10M 30.4 / 32.0 / 33.4
+                                                                                           -> u8p below 0.85 points per pixel, never u8v
+    Sizes in between take the rule of the nearer measured class (by the bytes of the doubled texture: up to 6 MB it lives in one XCD's L2,
+    up to 24 MB it is cfg 2's class)."""
     n, px = int(n), int(H) * int(W)
-    return "u8p" if 3 * n < px else "u8v" if 12 * n >= 5 * px else "u8"
+    doubled = 8 * (int(H) + 2) * (int(W) + 2)
+    if doubled <= 6_000_000:
+        return "u8v"
+    if doubled <= 24_000_000:
+        return "u8p" if 3 * n < px else "u8v" if 12 * n >= 5 * px else "u8"
+    return "u8p" if 20 * n < 17 * px else "u8"
 
 
 def _known_levels(img):

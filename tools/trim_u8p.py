@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Trim launch with row-major RGBA8 texels vs rows interleaved in pairs (PCL_PANO_U8P) vs vertical pairs (PCL_PANO_U8V): tables must agree
 bit for bit; ms per launch.
-   python tools/trim_u8p.py [n_points ...]"""
+   python tools/trim_u8p.py [n_points ...]        (PCL_TOOL_HW=2048x4096 for another panorama size)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from piccolo_amd import ops, synth, utils
-H, W = 1024, 2048
+H, W = [int(v) for v in os.environ.get("PCL_TOOL_HW", "1024x2048").split("x")]
 dev = torch.device("cuda:0")
 for n in [int(a) for a in sys.argv[1:]] or [166_667, 1_000_000]:
     xyz, rgb = synth.box_room(n, 0)
