@@ -125,14 +125,18 @@ class Pano:
 
 def refine_texels(n, H, W):
     """Level-texel format ("f16" | "u8") for the REFINEMENT of an n-point cloud against an H x W panorama.  fp16-level texels (8 B)
-    save 6 VALU instructions per point-pose and win where the loss kernel is VALU-bound (cfg 2: +4-5 %); a sparse cloud — fewer than
-    one point per three pixels — is bound by texture lines and latency instead (the 2 x 2 footprints of a wave's 128 Morton neighbours
-    share no cache line), and RGBA8 texels (4 B: half the texture in L2) win: measured per GD iteration with the starting poses
-    make_input hands over, 167k points on 2048 x 1024: 6 candidates 14.1 -> 12.0 us, 48 candidates (8 images per chain) 70.5 -> 45.4 us;
-    400k points 24.1 -> 19.8 us; at 1M points (0.48 points per pixel: cfg 2, which stays on fp16 levels) the two are within 2.5 % of each
-    other, fp16 ahead for poses near each other, RGBA8 for poses all over the room (tools/iter_latency.py).  The
-    formats give the same bits (tests/test_hip_parity.py::test_pano_format_selection_and_float_image)."""
-    return "u8" if 3 * int(n) < int(H) * int(W) else "f16"
+    save 6 VALU instructions per point-pose and win where the loss kernel is VALU-bound (cfg 2: +4-5 % for starting poses near each
+    other); a sparse cloud is bound by texture lines, latency and the L2 residency of the texture instead (the 2 x 2 footprints of a
+    wave's 128 Morton neighbours share no cache line), and RGBA8 texels (4 B: half the texture in L2) win.  Measured per GD iteration,
+    32 candidates all over the room (what make_input hands over; tools/refine_fmt_sweep.sh), f16 -> u8:
+        2048 x 1024: 167k points x 6 candidates 14.1 -> 12.0 us; 32 candidates: 400k 66.3 -> 57.2, 700k 86.5 -> 83.1, 1M 112.4 -> 109.6,
+                     2M 195.5 -> 199.4 (and with the candidates make_input really trims to at 1M: 11.4 -> 11.55 ms per refinement)
+        4096 x 2048: 2M 344.7 -> 226.7, 3M 396.6 -> 315.3, 4.5M 470.1 -> 454.2, 6M 584.6 -> 587.2, 8M 760.1 -> 766.9
+    i.e. RGBA8 up to ~0.5 points per pixel for spread poses at both sizes; the threshold sits at 0.45 so that cfg 2 (0.48 points per
+    pixel, where poses near each other — bench.py's — run 4-5 % faster on fp16 levels) stays on fp16.  (Round 4's threshold was 1/3:
+    it left 20 % on the table at 3M points on 4096 x 2048.)  The formats give the same bits
+    (tests/test_hip_parity.py::test_pano_format_selection_and_float_image)."""
+    return "u8" if 20 * int(n) < 9 * int(H) * int(W) else "f16"
 
 
 def trim_texels(n, H, W):

@@ -15,7 +15,7 @@ if N < 0:                  # sweep of the spread modes in one process: python to
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 spread = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-H, W = 1024, 2048
+H, W = [int(v) for v in os.environ.get("PCL_TOOL_HW", "1024x2048").split("x")]          # PCL_TOOL_HW=2048x4096: another panorama size
 dev = torch.device("cuda:0")
 xyz, rgb = synth.box_room(N, 0)
 X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
