@@ -8,7 +8,7 @@ from piccolo_amd import ops, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 166_667
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-H, W = 1024, 2048
+H, W = [int(v) for v in os.environ.get("PCL_TOOL_HW", "1024x2048").split("x")]
 dev = torch.device("cuda:0")
 xyz, rgb = synth.box_room(n, 0)
 X, C = torch.from_numpy(xyz).to(dev), torch.from_numpy(rgb).to(dev)
