@@ -342,6 +342,11 @@ static PclPlan pcl_plan(int64_t n, int B)
     // sweep an eighth of the room on its own, nothing it gathers is reused by a neighbour (5.08 -> 4.83 ms at 64 chunks)
     int64_t want = blocks_env / p.ngroups;
     if (want < 64) want = 64;
+    // large clouds (round 5): a chunk should stay a small piece of the room whatever the grid size asks for — at 4M points on a
+    // 4096 x 2048 panorama, 32 candidates all over the room, 512 chunks instead of 256: 447 -> 404 us per iteration; 10M points
+    // (cfg 5): 882 -> 869; 3M points on 2048 x 1024: 280 -> 282 (tools/iter_latency.py with PCL_BLOCKS).  Up to 2M points the
+    // grid-size rule alone is better (cfg 2's multi-image chains and cfg 3 lose 0.2-2 % with more chunks).
+    if (n > 2000000 && want < n / 8192) want = n / 8192;
     int64_t steps = (n + PCL_STEP - 1) / PCL_STEP;
     // small clouds under many poses (cfg 1 with 64 images per launch: 196 steps, 32 groups): blocks of one or two steps are
     // mostly prologue and epilogue — go for three steps per block as long as one round of resident blocks remains
@@ -386,8 +391,16 @@ void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int
 {
     PclPlan p = pcl_plan(n, 2 * ngroups);
     static const int chunks_env = pcl_env_int("PCL_TRIM_CHUNKS", 0);          // experiments
-    if (chunks_env >= 8) {
-        int64_t steps = (n + PCL_STEP - 1) / PCL_STEP, want = ((chunks_env + 7) / 8) * 8;
+    // Hundreds of slots share every chunk, so the plan above settles on its minimum of 64 chunks whatever the cloud — and a chunk of a
+    // large cloud is then a large piece of the room: at 4M points on 4096 x 2048 (62k points per chunk) the 1800-pose launch took 16.3 ms,
+    // with 20k points per chunk 13.3, with 8k 13.0; 10M points: 30.1 / 27.9 (20k) / 28.2 (10k) ms; at 2048 x 1024 the count hardly matters
+    // (1M: 3.19 / 3.18 / 3.26 ms at 16k / 8k / 4k points per chunk; 3M: 8.28 / 8.24 / 8.59 at 47k / 20k / 6k) — round 5, tools/trim_u8p.py
+    // with PCL_TRIM_CHUNKS.  Hence: at most 16k points per chunk (the refinement's large-cloud rule in pcl_plan, 8k, is a little worse
+    // here: 10M points 26.9 against 26.2 ms, 3M on 2048 x 1024 7.95 against 7.78).
+    int auto_chunks = 0;
+    if (chunks_env < 8 && n > (int64_t)64 * 16384) auto_chunks = (int)((n + 16383) / 16384);
+    if (chunks_env >= 8 || auto_chunks) {
+        int64_t steps = (n + PCL_STEP - 1) / PCL_STEP, want = (((chunks_env >= 8 ? chunks_env : auto_chunks) + 7) / 8) * 8;
         if (want > steps) want = ((steps + 7) / 8) * 8;
         p.nchunks = (int)want; p.steps_base = (int)(steps / want); p.steps_rem = (int)(steps % want);
         static const int runs_env = pcl_env_int("PCL_TRIM_RUNS", 0);

@@ -145,21 +145,24 @@ def trim_texels(n, H, W):
     kernel_and_oracle): plain rows `u8` (two 8-byte accesses per 2 x 2 footprint), rows interleaved in pairs `u8p` (1.5 accesses, same
     bytes, four selects per sample), vertical pairs `u8v` (ONE access, twice the texture).  Which one is fastest depends on what the
     launch is bound by — texture lines (sparse clouds), L2 residency of the texture under hundreds of concurrent views (large
-    panoramas), VALU issue (dense clouds) — measured per 1800-pose launch, ms (u8 / u8p / u8v):
+    panoramas), VALU issue (dense clouds) — measured per 1800-pose launch, ms (u8 / u8p / u8v), chunks of at most 16k points
+    (pcl_plan_for_groups):
         1024 x  512, u8v = 4 MB : 100k points 0.51 / 0.45 / 0.40, 250k 0.84 / 0.87 / 0.73, 500k 1.47 / 1.62 / 1.35    -> u8v always
         2048 x 1024, u8v = 17 MB: 167k 1.02 / 0.85 / 1.24, 400k 1.72 / 1.51 / 1.94, 700k 2.5 / 2.5 / 2.5, 850k 2.84 / 2.88 / 2.80,
-                                  1M 3.20 / 3.34 / 3.12, 2M 5.79 / 6.44 / 5.51            -> u8p below 1/3 point per pixel, u8v from 5/12
-        4096 x 2048, u8v = 67 MB: 3M 14.1 / 10.3 / 17.0, 6M 20.6 / 19.6 / 25.0, 8M 25.3 / 25.9 / 29.5, 10M 30.4 / 32.0 / 33.4
-                                                                                           -> u8p below 0.85 points per pixel, never u8v
-    Sizes in between take the rule of the nearer measured class (by the bytes of the doubled texture: up to 6 MB it lives in one XCD's L2,
-    up to 24 MB it is cfg 2's class)."""
+                                  1M 3.18 / 3.34 / 3.06, 2M 6.05 / 6.47 / 5.31, 3M 8.29 / 9.60 / 7.78
+                                                                                 -> u8p below 1/3 point per pixel, u8v from 5/12
+        4096 x 2048, u8v = 67 MB: 3M 11.1 / 10.2 / 13.6, 4M 13.1 / 13.4 / 14.7, 6M 17.7 / 19.8 / 16.9, 8M 22.8 / 26.1 / 21.2,
+                                  10M 28.0 / 32.5 / 26.2                         -> u8p below 0.45 points per pixel, u8v from 0.6
+    (With the 64 chunks per launch of rounds 3-4 the large panorama looked different — 10M points 30.4 / 32.0 / 33.4: every chunk was
+    a large piece of the room, and the doubled texture lost.)  Sizes in between take the rule of the nearer measured class (by the
+    bytes of the doubled texture: up to 6 MB it lives in one XCD's L2, up to 24 MB it is cfg 2's class)."""
     n, px = int(n), int(H) * int(W)
     doubled = 8 * (int(H) + 2) * (int(W) + 2)
     if doubled <= 6_000_000:
         return "u8v"
     if doubled <= 24_000_000:
         return "u8p" if 3 * n < px else "u8v" if 12 * n >= 5 * px else "u8"
-    return "u8p" if 20 * n < 17 * px else "u8"
+    return "u8p" if 20 * n < 9 * px else "u8v" if 5 * n >= 3 * px else "u8"
 
 
 def _known_levels(img):

@@ -285,7 +285,7 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
         with pytest.raises(Exception):                     # nothing but the trim launch reads these layouts
             ops.sampling_loss(cloud, ops.Pano(img, fmt=paired), T(trans[:2]), T(stanford[:2]))
     assert [ops.trim_texels(n_, 1024, 2048) for n_ in (166_667, 700_000, 1_000_000)] == ["u8p", "u8", "u8v"]
-    assert [ops.trim_texels(n_, 2048, 4096) for n_ in (4_000_000, 10_000_000)] == ["u8p", "u8"] and ops.trim_texels(100_000, 512, 1024) == "u8v"
+    assert [ops.trim_texels(n_, 2048, 4096) for n_ in (3_000_000, 4_000_000, 10_000_000)] == ["u8p", "u8", "u8v"] and ops.trim_texels(100_000, 512, 1024) == "u8v"
     # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once
     groups = ops.TrimGroups(T(stanford))
     want = ops.trim_loss_table(cloud, ops.Pano(img, fmt="u8"), T(trans), groups).cpu().numpy()
