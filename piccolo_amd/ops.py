@@ -355,7 +355,7 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
     # 0.5 ms at 167k points); a batch is kept within ~8 GB (10M points: 16 candidates at a time).
     # pcl_hist_trim_workspace_bytes_n is the binned path's size where that path will be taken, the splat path's otherwise.
     per_cand = max(lib.pcl_hist_trim_workspace_bytes_n(cloud.n, 1, H, W, num_split_h, num_split_w), 1)
-    batch = max(1, min(batch, K, int(8e9 // per_cand)))
+    batch = max(1, min(batch, K, int(HIST_BATCH_BYTES // per_cand)))
     if lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w) == 0:
         raise ValueError("hist_trim_scores: need num_split_h >= 3 and blocks of at least one pixel")
     ws = None
@@ -385,6 +385,8 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
 
 
 HIST_MAX_IMAGES = 32       # pcl_hist_trim_scores_images: query images per call
+# bytes of point lists one histogram-trim call may hold (experiments: PCL_HIST_BATCH_BYTES)
+HIST_BATCH_BYTES = float(os.environ.get("PCL_HIST_BATCH_BYTES", "8e9"))
 
 
 def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
@@ -408,7 +410,7 @@ def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
     per_image = lib.pcl_hist_trim_images_workspace_bytes(cloud.n, 1, K, H, W, num_split_h, num_split_w)
     if per_image == 0:
         raise ValueError("hist_trim_scores_images: need num_split_h >= 3 and blocks of at least one pixel")
-    group = max(1, min(HIST_MAX_IMAGES, I, int(8e9 // per_image)))
+    group = max(1, min(HIST_MAX_IMAGES, I, int(HIST_BATCH_BYTES // per_image)))
     t2, r2 = trans.reshape(I * K, 3).contiguous(), rot.reshape(I * K, 3).contiguous()
     i0 = 0
     while i0 < I:
