@@ -131,10 +131,10 @@ def refine_texels(n, H, W):
     32 candidates all over the room (what make_input hands over; tools/refine_fmt_sweep.sh), f16 -> u8:
         2048 x 1024: 167k points x 6 candidates 14.1 -> 12.0 us; 32 candidates: 400k 66.3 -> 57.2, 700k 86.5 -> 83.1, 1M 112.4 -> 109.6,
                      2M 195.5 -> 199.4 (and with the candidates make_input really trims to at 1M: 11.4 -> 11.55 ms per refinement)
-        4096 x 2048: 2M 344.7 -> 226.7, 3M 396.6 -> 315.3, 4.5M 470.1 -> 454.2, 6M 584.6 -> 587.2, 8M 760.1 -> 766.9
+        4096 x 2048: 2M 344.7 -> 226.7, 3M 348.0 -> 318.9, 4M 410.7 -> 407.3, 4.5M 455.1 -> 456.7, 6M 581.6 -> 589.3, 8M 760.1 -> 766.9
     i.e. RGBA8 up to ~0.5 points per pixel for spread poses at both sizes; the threshold sits at 0.45 so that cfg 2 (0.48 points per
     pixel, where poses near each other — bench.py's — run 4-5 % faster on fp16 levels) stays on fp16.  (Round 4's threshold was 1/3:
-    it left 20 % on the table at 3M points on 4096 x 2048.)  The formats give the same bits
+    it left 8 % on the table at 3M points on 4096 x 2048 — 20 % before the chunks of large clouds were made smaller, pcl_plan.)  The formats give the same bits
     (tests/test_hip_parity.py::test_pano_format_selection_and_float_image)."""
     return "u8" if 20 * int(n) < 9 * int(H) * int(W) else "f16"
 
