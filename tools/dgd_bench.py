@@ -12,7 +12,8 @@ from piccolo_amd import ops, synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-H, W = 1024, 2048
+import os
+H, W = [int(v) for v in os.environ.get("PCL_TOOL_HW", "1024x2048").split("x")]
 xyz, rgb = synth.box_room(N, 0)
 X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
 t, ypr = synth.gt_pose(0)
@@ -25,7 +26,7 @@ h1, w1, t1, _ = ops.default_depth(N, H, W, stride=1)
 rows = [("plain", dict(depth_mask=False)), ("mask, default: grid %dx%d tau %.3f stride %d" % (dw, dh, dtau, dst), dict(depth_mask=True)),
         ("mask, every point: grid %dx%d tau %.3f stride 1" % (w1, h1, t1), dict(depth_mask=True, depth_stride=1))]
 if B <= 64:
-    rows.append(("mask, panorama grid 2048x1024 tau 0.02 (round 4's)", dict(depth_mask=True, depth_res=(H, W), depth_tau=0.02)))
+    rows.append(("mask, panorama grid %dx%d tau 0.02 (round 4's)" % (W, H), dict(depth_mask=True, depth_res=(H, W), depth_tau=0.02)))
 base = None
 for name, kw in rows:
     ts = []
