@@ -265,7 +265,7 @@ size_t pcl_hist_trim_workspace_bytes(int ncand, int H, int W, int nsh, int nsw);
 /* Same for a cloud of n points, large enough for the tile-binned render (ABI v4): every candidate's points are binned by the
  * 64 x 64-pixel image tile(s) their 3 x 3 splat touches and every tile is resolved and histogrammed in LDS — no z-buffer in
  * HBM, bit-identical scores.  pcl_hist_trim_scores takes that path when its workspace is at least this large (4 n list
- * entries of 12 bytes per candidate: the exact worst case; plus 8 n bytes for the projections the count pass hands to the scatter pass)
+ * entries of 12 bytes per candidate: the exact worst case; plus the tiles' run tables, 8 bytes x tiles x ceil(n / 2048) per candidate)
  * and the z-buffer splat otherwise. */
 size_t pcl_hist_trim_workspace_bytes_n(int64_t n, int ncand, int H, int W, int nsh, int nsw);
 int pcl_hist_trim_scores(const float *cloud, int64_t n, const float *img_hwc, int H, int W, const float *trans,
