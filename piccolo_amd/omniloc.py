@@ -156,8 +156,10 @@ def _rot_matrix(ypr):
 # pcl_gd_run neither allocates nor synchronises, every candidate reads its panorama through its pose record
 # (pcl_gd_set_panos), so a new image only needs pcl_gd_init + pcl_gd_set_panos + one graph launch.  Replay is
 # bit-identical to the eager launches (tests).  Measured at cfg 1: 0.65 vs 0.73 ms per refinement; nothing at cfg 2
-# (110 us kernels), hence the size limit.
-GRAPH_POINT_POSES = 4_000_000          # use graph replay when points x candidates is at most this (cfg key gd_graph overrides)
+# (110 us kernels), hence the size limit.  Round 5: between 4M and 16M point-poses (1M points x 6 candidates, 400k x 32: 15-30 us
+# launches) the medians are the same, but an eager chain now and then loses a millisecond to the host thread (3.3 -> 4.4 ms, 5.2 -> 6.2 ms
+# seen at 1M / 2M points x 6 candidates; never with replay): the limit went from 4M to 16M.
+GRAPH_POINT_POSES = 16_000_000         # use graph replay when points x candidates is at most this (cfg key gd_graph overrides)
 
 
 def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
