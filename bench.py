@@ -71,24 +71,45 @@ def self_launch(argv):
     env = dict(os.environ)
     # dmabuf IPC: on this pool's host driver RCCL between processes fails with `hipIpcGetMemHandle: invalid argument` under the
     # legacy IPC mode.  A DEFAULT only: a value already in the environment (the driver's, or PCL_HSA_IPC_MODE_LEGACY to force one
-    # for an experiment) wins, and every rank prints the value it runs with.
+    # for an experiment) wins, and every rank prints the value it runs with and where it came from.
     if "PCL_HSA_IPC_MODE_LEGACY" in env:
-        env["HSA_ENABLE_IPC_MODE_LEGACY"] = env["PCL_HSA_IPC_MODE_LEGACY"]
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["HSA_ENABLE_IPC_MODE_LEGACY"], env["PCL_IPC_MODE_FROM"] = env["PCL_HSA_IPC_MODE_LEGACY"], "override"
+    elif "HSA_ENABLE_IPC_MODE_LEGACY" in env:
+        env["PCL_IPC_MODE_FROM"] = "environment"
+    else:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"], env["PCL_IPC_MODE_FROM"] = "0", "default"
     env.setdefault("OMP_NUM_THREADS", "1")                   # (torchrun would set it, with a warning; cpu_baseline sizes its own pool)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", port, "--", os.path.abspath(__file__)] + list(argv)
-    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=os.getcwd())
-    last_json = None
-    for ln in child.stdout:                                  # everything the ranks print goes to stderr as it comes ...
-        if ln.startswith("{") and ln.rstrip().endswith("}"):
-            last_json = ln.rstrip("\n")
-        else:
-            sys.stderr.write(ln)
-    rc = child.wait()
-    sys.stderr.flush()
-    if last_json is not None:                                # ... and rank 0's line is the one line on stdout
+    rc, last_json = 1, None
+    for attempt in (0, 1):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", port, "--", os.path.abspath(__file__)] + list(argv)
+        print("bench.py: launching %d ranks (HSA_ENABLE_IPC_MODE_LEGACY=%s, %s): %s" % (n, env["HSA_ENABLE_IPC_MODE_LEGACY"], env["PCL_IPC_MODE_FROM"],
+                                                                                       " ".join(cmd)), file=sys.stderr, flush=True)
+        # one pipe for the ranks' stdout AND stderr (each line is one write below PIPE_BUF: never spliced): everything they print goes
+        # to the launcher's stderr as it comes, rank 0's compact JSON line alone goes to stdout at the end
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=os.getcwd())
+        last_json, collective_failed = None, False
+        for ln in child.stdout:
+            if ln.startswith("{") and ln.rstrip().endswith("}"):
+                last_json = ln.rstrip("\n")
+            else:
+                sys.stderr.write(ln)
+                collective_failed |= "bench.py rank" in ln and " FAILED: " in ln
+        rc = child.wait()
+        sys.stderr.flush()
+        if rc == 0 or last_json is not None or not collective_failed or attempt == 1 or env["PCL_IPC_MODE_FROM"] == "override":
+            break
+        # A collective (or the process group's set-up) failed on some rank.  The one known cause on this pool is the IPC mode; the first
+        # real multi-GPU run must still produce a line, so ONE more launch of fresh rank processes with the other mode (a new
+        # subprocess from this launcher, which has never touched the GPU — never a re-exec of a rank).
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1" if env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" else "0"
+        env["PCL_IPC_MODE_FROM"] = "retry"
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+        print("bench.py: a collective failed (rc %d, no JSON line): launching once more with HSA_ENABLE_IPC_MODE_LEGACY=%s"
+              % (rc, env["HSA_ENABLE_IPC_MODE_LEGACY"]), file=sys.stderr, flush=True)
+    if last_json is not None:                                # rank 0's line is the one line on stdout
         print(last_json, flush=True)
     if rc == 0 and last_json is None:
         print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
@@ -241,19 +262,26 @@ class Ranks:
         # dmabuf IPC for RCCL / tensor sharing between the ranks' processes (the pool's driver supports nothing else): the HSA runtime
         # reads this when the process first touches the GPU, so it is set BEFORE torch.cuda.set_device below — setting it next to
         # init_process_group, as rounds 1-4 did, only worked because the boxes export it already
-        if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:                 # (experiments: what happens without dmabuf IPC)
-            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self.ipc_from = os.environ.get("PCL_IPC_MODE_FROM")          # set by the launcher: default / environment / override / retry
+        if self.ipc_from is None:
+            if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:             # (experiments: what happens without dmabuf IPC)
+                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"], self.ipc_from = os.environ["PCL_HSA_IPC_MODE_LEGACY"], "override"
+            elif "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+                self.ipc_from = "environment"
+            else:
+                os.environ["HSA_ENABLE_IPC_MODE_LEGACY"], self.ipc_from = "0", "default"
+        self.ipc_mode = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        self.test_fail_nccl = os.environ.get("PCL_BENCH_TEST_FAIL_NCCL") == "1"     # (test hook: RCCL's set-up "fails" on every rank)
         self.n_dev = torch.cuda.device_count()
         if self.n_dev < 1:
             raise SystemExit("bench.py needs an MI355X: torch.cuda.device_count() == 0")
-        if self.backend == "nccl" and self.n_dev < args.gpus:
+        if self.backend == "nccl" and self.n_dev < args.gpus and not self.test_fail_nccl:
             raise SystemExit("--gpus %d but only %d GPU(s) are visible to this process (torch.cuda.device_count()): one rank per "
                              "GPU is required for the RCCL run" % (args.gpus, self.n_dev))
-        dev_index = local_rank % self.n_dev if self.backend != "nccl" else local_rank
+        dev_index = local_rank % self.n_dev if (self.backend != "nccl" or self.test_fail_nccl) else local_rank
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
-        self.dist = None
+        self.dist, self.fallback = None, None
         if self.world > 1 or os.environ.get("PCL_BENCH_FORCE_DIST") == "1":   # (the env knob exercises the RCCL path at world size 1)
             import datetime
             import torch.distributed as dist
@@ -269,17 +297,45 @@ class Ranks:
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if self.backend == "nccl" else "-"
             except Exception as exc:                                # noqa: BLE001
                 rccl = "unknown (%s)" % exc
-            print("bench.py rank %d/%d: pid %d, device cuda:%d of %d visible (%s), backend %s, RCCL %s, HSA_ENABLE_IPC_MODE_LEGACY=%s, "
+            print("bench.py rank %d/%d: pid %d, device cuda:%d of %d visible (%s), backend %s, RCCL %s, HSA_ENABLE_IPC_MODE_LEGACY=%s (from: %s), "
                   "rendezvous %s:%s, timeout %.0f s" % (self.rank, self.world, os.getpid(), dev_index, self.n_dev, torch.cuda.get_device_name(dev_index),
-                                                        self.backend, rccl, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), os.environ["MASTER_ADDR"],
+                                                        self.backend, rccl, self.ipc_mode, self.ipc_from, os.environ["MASTER_ADDR"],
                                                         os.environ["MASTER_PORT"], self.timeout_s), file=sys.stderr, flush=True)
+            if os.environ.get("PCL_BENCH_TEST_FAIL_IF_IPC") == self.ipc_mode:       # (test hook of the launcher's one retry)
+                self.fail("init_process_group(%s)" % self.backend, RuntimeError("PCL_BENCH_TEST_FAIL_IF_IPC=%s" % self.ipc_mode))
             try:
                 if self.backend == "nccl":
+                    if self.test_fail_nccl:
+                        raise RuntimeError("PCL_BENCH_TEST_FAIL_NCCL")
                     dist.init_process_group("nccl", device_id=self.dev, timeout=tmo)     # RCCL
+                    probe = torch.ones(1, device=self.dev)                               # the communicator's first use, inside the try:
+                    dist.all_reduce(probe)                                               # IPC handles are exchanged here
+                    torch.cuda.synchronize()
+                    assert int(probe.item()) == self.world, (float(probe.item()), self.world)
                 else:
                     dist.init_process_group(self.backend, timeout=tmo)
             except Exception as exc:                                # noqa: BLE001
-                self.fail("init_process_group(%s)" % self.backend, exc)
+                if self.backend != "nccl" or os.environ.get("PCL_NO_GLOO_FALLBACK") == "1" or self.ipc_from in ("default", "environment") and "PCL_IPC_MODE_FROM" in os.environ:
+                    # (under bench.py's own launcher the first failure ends the job with rc 3: the launcher tries the other IPC mode once)
+                    self.fail("init_process_group(%s)" % self.backend, exc)
+                # Started by someone else's torch.distributed.run (the driver's N > 1 command) or already on the launcher's second
+                # attempt: there is no further launch to hope for.  The path's ONLY collective is the gather of 16 floats per image, so
+                # the run goes on with it over host memory (gloo) and says so in the line — a measured value with a labelled
+                # transport instead of no line at all.
+                print("bench.py rank %d/%d: RCCL set-up FAILED (%s: %s): falling back to gloo for the result gather"
+                      % (self.rank, self.world, type(exc).__name__, str(exc).replace("\n", " | ")[:300]), file=sys.stderr, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:                                   # noqa: BLE001
+                    pass
+                try:
+                    dist.init_process_group("gloo", init_method="tcp://%s:%d" % (os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1),
+                                            rank=self.rank, world_size=self.world, timeout=tmo)
+                except Exception as exc2:                           # noqa: BLE001
+                    self.fail("init_process_group(gloo fallback)", exc2)
+                self.backend = "gloo"
+                self.fallback = "RCCL set-up failed (%s): result gather over gloo" % type(exc).__name__
             self.dist = dist
         self.coll_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
 
@@ -728,6 +784,105 @@ def depth_mask_block(sc, B, n_images=2, panorama_grid=True):
     return out
 
 
+COMPACT_LIMIT = 4096            # bytes: the LAST stdout line must stay below this (the driver keeps an 8 KB tail of stdout)
+
+
+def _r(v, sig=6):
+    """floats rounded to `sig` significant digits (the compact line is for parsing, the full precision is in the side file)"""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (sig, v))
+
+
+def _pick(d, keys):
+    return {k: _r(d.get(k)) for k in keys if d is not None and k in d}
+
+
+def compact_line(full, also_path=None):
+    """The ONE line the driver parses: headline, config, single_image, roofline, cpu_baseline, checks — numbers and short names only,
+    always below COMPACT_LIMIT bytes.  Everything else of `full` (the `also` block, per-kernel roofs, the prose `*_is` strings) goes to
+    the side file `also_path` (bench_also.json), never to the last stdout line: BENCH_r05.parsed was null because the line had grown
+    to 24.5 KB."""
+    cfg, roof, single, cpu = full.get("config") or {}, full.get("roofline") or {}, full.get("single_image"), full.get("cpu_baseline")
+    valu = roof.get("valu") or {}
+    alg, hbm = roof.get("algorithmic_hbm") or {}, roof.get("hbm_measured") or {}
+    line = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                         "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:160]}
+    line["config"].update(_pick(cfg, ("images_per_launch", "poses_per_launch", "texels", "images_per_gpu", "mode")))
+    if single:
+        line["single_image"] = _pick(single, ("value", "ms_per_step", "poses_per_launch", "valu_frac", "avg_launch_ms"))
+        line["single_image"]["workload"] = "literal %s: ONE query image per launch chain" % str(cfg.get("workload", "")).split(" ")[0]
+    rl = _pick(roof, ("bound", "achieved", "peak", "unit", "frac"))
+    rl["kernel"] = str(roof.get("kernel", ""))[:80]
+    rl.update(_pick(roof, ("avg_launch_ms", "launches_timed", "traffic")))
+    rl["algorithmic_hbm_frac"], rl["hbm_measured_frac"] = _r(alg.get("frac")), _r(hbm.get("frac_of_peak"))
+    rl.update(_pick(valu, ("instr_per_point_pose", "busy_frac_profiled", "mix_ceiling_cycles_per_instr", "frac_of_mix_ceiling", "fp32_flop_frac")))
+    rl["profile"] = str(valu.get("source", roof.get("traffic_key", "")))[:60]
+    rl["source_hash"] = roof.get("source_hash_loaded_library")
+    line["roofline"] = rl
+    if cpu:
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "pose_evals_per_s"))
+        line["cpu_baseline"]["sample"] = str(cpu.get("sample", ""))[:150]
+        e2e = cpu.get("cfg1_end_to_end")
+        if e2e:
+            line["cpu_baseline"]["cfg1_end_to_end"] = _pick(e2e, ("t_err_m", "r_err_deg", "seconds"))
+    line["checks"] = _pick(full.get("checks") or {}, ("kernel_ms_per_step", "kernel_time_within_step", "kernel_share_of_step"))
+    line.update(_pick(full, ("ranks_seen", "devices_visible", "dist_backend", "passes", "median_t_err_m", "median_r_err_deg")))
+    pr = full.get("per_rank_ms_per_step")
+    if pr:
+        line["per_rank_ms_per_step"] = _pick(pr, ("min", "max"))
+    n1 = full.get("n1_value_same_build")
+    if n1:
+        line["n1_value_same_build"] = _pick(n1, ("value", "ms_per_step"))
+    line.update(_pick(full, ("pass_ms", "ipc_mode_legacy", "ipc_mode_from")))
+    if full.get("dist_fallback"):
+        line["dist_fallback"] = str(full["dist_fallback"])[:100]
+    if "pass_ms" in line and isinstance(line["pass_ms"], dict):
+        line["pass_ms"] = {k: _r(v) for k, v in line["pass_ms"].items()}
+    also = full.get("also") or {}
+    brief = {}
+    for k, v in also.items():                                   # one number per side measurement; the blocks themselves are in the side file
+        if isinstance(v, dict):
+            for key in ("value", "total_ms", "total_ms_per_image"):
+                if key in v:
+                    brief[k] = _r(v[key], 5)
+                    break
+    if "depth_mask_cfg2" in also and isinstance(also["depth_mask_cfg2"], dict):
+        for name in ("plain", "default_grid", "every_point"):
+            if name in also["depth_mask_cfg2"]:
+                brief["depth_mask_cfg2." + name] = _r(also["depth_mask_cfg2"][name].get("value"), 5)
+    if also.get("error"):
+        brief["error"] = str(also["error"])[:120]
+    if brief:
+        line["also_brief"] = brief
+    if also_path:
+        line["also_file"] = os.path.relpath(also_path, REPO) if also_path.startswith(REPO) else also_path
+    # the size is a contract, not a hope: shed the optional blocks, least important first, until the line fits
+    for drop in ("also_brief", "pass_ms", "n1_value_same_build", "per_rank_ms_per_step", "checks", "single_image"):
+        if len(json.dumps(line)) < COMPACT_LIMIT - 64:
+            break
+        line.pop(drop, None)
+    assert len(json.dumps(line)) < COMPACT_LIMIT, len(json.dumps(line))
+    return line
+
+
+def emit(full, also_path):
+    """side file first (the complete record), then the compact line as the LAST line of stdout"""
+    if also_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(also_path)), exist_ok=True)
+            with open(also_path, "w") as f:
+                json.dump(full, f, indent=1)
+            print("bench.py: complete record (also / kernel_roofs / notes) written to %s" % also_path, file=sys.stderr, flush=True)
+        except OSError as exc:
+            print("bench.py: could not write %s: %s" % (also_path, exc), file=sys.stderr, flush=True)
+            also_path = None
+    print(json.dumps(compact_line(full, also_path)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -751,6 +906,9 @@ def main():
                          "clocks (first run after boot measured 3137 vs 3300 candidate-poses/s with --warmup 2)")
     ap.add_argument("--roofs-json", default=os.path.join(REPO, "profiles", "roofs.json"),
                     help="per-launch-shape counter figures from the rocprofv3 PMC passes (profiles/collect.sh)")
+    ap.add_argument("--also-json", default=os.path.join(REPO, "bench_also.json"),
+                    help="side file for the COMPLETE record (the `also` block, per-kernel roofs, notes); the last stdout line is the compact "
+                         "line only ('' = no side file)")
     args = ap.parse_args()
 
     ranks = Ranks(args)
@@ -889,10 +1047,9 @@ def main():
             "metric": "candidate-poses/s", "value": value, "unit": "candidate-poses/s", "n_gpus": world, "steps": K,
             "warmup": Wm, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s x %d query images per launch chain%s: %d-point cloud, %dx%d panorama, %d candidate poses x %d GD "
-                                   "iterations per query image, %d poses per launch; the literal one-image-per-chain %s is `single_image`"
+            "config": {"workload": "%s x %d images per launch chain%s: %d-pt cloud, %dx%d pano, %d candidates x %d GD iterations per image"
                                    % (args.workload, ipl, " (cfg 4's shape on one GPU)" if args.workload == "cfg2" and ipl > 1 else "",
-                                      N, W, H, B, NUM_ITER, ipl * B, args.workload),
+                                      N, W, H, B, NUM_ITER),
                        "images_per_gpu": K, "sharding": "query images round-robin over ranks, RCCL all_gather of results",
                        "mode": "omniloc_batch" if batch_mode else "omniloc", "images_per_launch": ipl,
                        "poses_per_launch": ipl * B, "texels": fmt_name, "warmup_images": "distinct from the timed ones"},
@@ -901,7 +1058,8 @@ def main():
             "per_rank_ms_per_step": {"min": min(per_rank_s) / K * 1e3, "max": max(per_rank_s) / K * 1e3, "ranks": [v / K * 1e3 for v in per_rank_s],
                                      "is": "each rank's own wall time for the median pass's K steps (+ its side of the gather), before "
                                            "the closing barrier; ms_per_step is the barrier-to-barrier time, MAX over ranks"},
-            "dist_backend": ranks.backend if ranks.dist is not None else None,
+            "dist_backend": ranks.backend if ranks.dist is not None else None, "dist_fallback": ranks.fallback,
+            "ipc_mode_legacy": ranks.ipc_mode, "ipc_mode_from": ranks.ipc_from,
             "pose_evals_per_s": value * NUM_ITER,
             "median_t_err_m": float(np.median(errs[:, 0])), "median_r_err_deg": float(np.median(errs[:, 1])),
             "single_image": single,
@@ -960,7 +1118,7 @@ def main():
         line["also"] = also
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sc.xyz, sc.rgb, img0_host, start0_host[0], start0_host[1], budget_s=args.cpu_baseline_seconds)
-    print(json.dumps(line), flush=True)
+    emit(line, args.also_json)
 
 
 if __name__ == "__main__":

@@ -41,8 +41,15 @@ def main():
     if cfg.dataset not in ("Synthetic", "Stanford2D-3D-S", "OmniScenes"):
         raise ValueError(cfg.dataset)
     import numpy as np
+    multi_rank = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi_rank:
+        # dmabuf IPC (bench.py): the HSA runtime reads this when the process first touches the GPU, so it is set
+        # before torch is imported and before anything counts or selects a device
+        if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if multi_rank:
         import torch
         # One process per GPU over RCCL.  PCL_DIST_BACKEND=gloo (the knob bench.py has) lets several ranks share the GPUs that
         # are there — how the test-suite runs this very loop with two ranks on a one-GPU box.
@@ -53,9 +60,6 @@ def main():
         if backend == "nccl" and n_dev <= local_rank:
             raise SystemExit("local rank %d but only %d GPU(s) visible: one rank per GPU is required for the RCCL run" % (local_rank, n_dev))
         import datetime
-        if "PCL_HSA_IPC_MODE_LEGACY" in os.environ:
-            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ["PCL_HSA_IPC_MODE_LEGACY"]
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (bench.py)
         dev_index = local_rank if backend == "nccl" else local_rank % n_dev
         torch.cuda.set_device(dev_index)
         # an explicit, short timeout: a rank that cannot reach the others ends with a reason instead of hanging for torch's 10-30 minutes

@@ -80,3 +80,94 @@ if rank == 0:
     bad = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=_clean_env(FAIL_RANK="1"), cwd=str(tmp_path),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "cpu_baseline", "checks", "ranks_seen", "per_rank_ms_per_step", "single_image")
+
+
+def _check_compact(c, full):
+    import json
+    text = json.dumps(c)
+    assert len(text) < 4096, len(text)
+    assert not [k for k in REQUIRED if k not in c], [k for k in REQUIRED if k not in c]
+    assert "also" not in c and c["config"]["workload"] and "model" not in c["config"]
+    r = c["roofline"]
+    assert set(r) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_hbm_frac", "hbm_measured_frac"}
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert set(c["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    for k in ("value", "ms_per_step"):
+        assert abs(c[k] - full[k]) <= 1e-5 * abs(full[k])
+    assert c["n_gpus"] == full["n_gpus"] and c["steps"] == full["steps"] and c["warmup"] == full["warmup"]
+    assert not [v for v in c.values() if isinstance(v, str) and len(v) > 200]
+
+
+def test_compact_line_of_recorded_full_lines_is_below_4k_with_every_key():
+    """the driver could not parse round 5's 24.5 KB line.  The LAST stdout line is now compact_line(record): on
+    the complete records of round 5 — the driver's N = 1 command and the self-launched 8-rank gloo run — it stays below 4 KB and
+    carries the headline, config, single_image, roofline, cpu_baseline and checks; the rest lives in the side file."""
+    import json
+    import bench
+    for name in ("bench_driver_command_line.json", "bench_gpus8_self_launched_gloo_one_gpu.json"):
+        full = json.load(open(os.path.join(REPO, "profiles", "r05", name)))
+        assert len(json.dumps(full)) > 4096                     # (what the driver lost, or nearly)
+        c = bench.compact_line(full, os.path.join(REPO, "bench_also.json"))
+        _check_compact(c, full)
+        assert c["also_file"] == "bench_also.json" and c["also_brief"]
+    assert c["n_gpus"] == 8 and c["ranks_seen"] == 8 and c["n1_value_same_build"]["value"] > 0 and c["dist_backend"] == "gloo"
+
+
+def test_compact_line_sheds_optional_blocks_instead_of_growing():
+    """The size is enforced, not hoped for: absurdly long strings and a huge `also` block still give a line below the limit with the
+    headline, the roofline and the CPU baseline intact; non-finite floats become null (valid JSON for any parser)."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(REPO, "profiles", "r05", "bench_driver_command_line.json")))
+    full["config"]["workload"] = "w" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    full["also"] = {"side_%d" % i: {"value": float(i)} for i in range(400)}
+    full["also"]["error"] = "e" * 5000
+    full["roofline"]["valu"]["frac"] = float("nan")
+    full["median_t_err_m"] = float("inf")
+    c = bench.compact_line(full, None)
+    text = json.dumps(c)
+    assert len(text) < bench.COMPACT_LIMIT and "NaN" not in text and "Infinity" not in text
+    assert c["value"] == bench._r(full["value"]) and c["roofline"]["frac"] and c["cpu_baseline"]["value"] and "also_brief" not in c
+    assert c["median_t_err_m"] is None
+
+
+def test_launcher_retries_once_with_the_other_ipc_mode(tmp_path):
+    """if a collective (or the process group's set-up) fails on the first launch, the launcher starts fresh ranks ONCE
+    more with the other HSA_ENABLE_IPC_MODE_LEGACY and relays that launch's line; the line says where the mode came from.  A value
+    forced with PCL_HSA_IPC_MODE_LEGACY is never second-guessed.  Stand-in rank body as above."""
+    import json
+    src = open(BENCH).read()
+    head = src[:src.index("import numpy as np")]
+    body = '''
+import json
+rank = int(os.environ["RANK"])
+mode = os.environ["HSA_ENABLE_IPC_MODE_LEGACY"]
+if mode == os.environ["FAIL_IF_IPC"]:
+    print("bench.py rank %d/2: init_process_group(nccl) FAILED: RuntimeError: hipIpcGetMemHandle: invalid argument" % rank, file=sys.stderr, flush=True)
+    os._exit(3)
+if rank == 0:
+    print(json.dumps({"ipc_mode_legacy": mode, "ipc_mode_from": os.environ["PCL_IPC_MODE_FROM"]}), flush=True)
+'''
+    script = tmp_path / "fake_bench.py"
+    script.write_text(head + body)
+    env = _clean_env(FAIL_IF_IPC="0")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    out = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip()) == {"ipc_mode_legacy": "1", "ipc_mode_from": "retry"}
+    assert out.stderr.count("launching 2 ranks") == 2 and "launching once more with HSA_ENABLE_IPC_MODE_LEGACY=1" in out.stderr
+    # the mode of the environment works: one launch, and the line says "environment"
+    ok = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="1"), cwd=str(tmp_path),
+                        capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0 and json.loads(ok.stdout.strip()) == {"ipc_mode_legacy": "1", "ipc_mode_from": "environment"}
+    assert ok.stderr.count("launching 2 ranks") == 1
+    # both modes fail: two launches, non-zero, no line
+    bad = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=dict(env, FAIL_IF_IPC="0", PCL_HSA_IPC_MODE_LEGACY="0"), cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and bad.stdout.strip() == "" and bad.stderr.count("launching 2 ranks") == 1      # forced mode: no retry
