@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 8 /* 8: PCL_PANO_U8V / pcl_pano_pack_u8v; 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
+#define PCL_ABI_VERSION 9 /* 9: pcl_gd_hyper.fuse, pcl_loss_depth_workspace_bytes takes the occluder stride, the library reads no environment variable; 8: PCL_PANO_U8V / pcl_pano_pack_u8v; 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -114,8 +114,10 @@ size_t pcl_loss_workspace_bytes(int64_t n, int B);
 /* The same with the scatter-min depth mask OF THE SAME POSES multiplied into the mask (build-defined; see pcl_depth_mask below for
  * the definition): the z-buffers of the B poses are built on a depth_h x depth_w grid from every depth_stride-th point (0 x 0 / 0:
  * pcl_depth_default) and the loss kernel looks every point's cell up — what one depth-masked GD iteration evaluates.  Equal to
- * pcl_depth_mask on that grid / stride followed by pcl_sampling_loss(visible = that mask).  workspace: pcl_loss_depth_workspace_bytes (0 for an invalid grid). */
-size_t pcl_loss_depth_workspace_bytes(int64_t n, int B, int H, int W, int depth_h, int depth_w);
+ * pcl_depth_mask on that grid / stride followed by pcl_sampling_loss(visible = that mask).  workspace: pcl_loss_depth_workspace_bytes
+ * with the SAME depth_h / depth_w / depth_stride (the default grid depends on the stride; 0 for an invalid grid).  depth_stride 1, 2 and 4
+ * have coalesced z passes; other strides (<= 64) are accepted and slower than reading every point.  depth_h, depth_w < 2^24. */
+size_t pcl_loss_depth_workspace_bytes(int64_t n, int B, int H, int W, int depth_h, int depth_w, int depth_stride);
 int pcl_sampling_loss_depth(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans,
                             const float *rot, int B, int with_grad, int depth_h, int depth_w, float tau, int depth_stride, float *result,
                             void *workspace, size_t workspace_bytes, void *stream);
@@ -159,6 +161,8 @@ typedef struct pcl_gd_hyper {
     int32_t depth_w;    /* density, NOT the panorama's resolution.  0 x 0: pcl_depth_default(n, H, W, depth_stride).                         */
     int32_t depth_stride; /* the z-buffers are built from every depth_stride-th point of the packed cloud (every point is still TESTED       */
                         /* against them).  0: pcl_depth_default's choice with a default grid, 1 with a given grid.                           */
+    int32_t fuse;          /* 0: pcl_gd_plan's rule (ONE launch per iteration when every block of the launch is resident at once).     */
+                           /* < 0: never — always loss launch + epilogue launch.  Same bits either way (tests compare the two forms).  */
     int32_t images;        /* number of query images whose candidates share this launch chain (pcl_gd_set_panos / _set_pano_groups;   */
                            /* image i's candidates a contiguous range).  0 / 1: one image.  A hint for the block -> XCD mapping only    */
                            /* (with several panoramas every XCD takes a range of pose groups, i.e. of images, over the whole cloud      */

@@ -11,7 +11,7 @@ from . import build as _build
 _c = ctypes
 _vp, _i64, _int, _sz, _dbl = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t, _c.c_double
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 RESULT_STRIDE = 8
 GD_RESULT_STRIDE = 16
 GD_SEQUENTIAL, GD_BATCH = 0, 1
@@ -21,7 +21,7 @@ PANO_F32, PANO_U8, PANO_F16, PANO_U8P, PANO_U8V = 0, 1, 2, 3, 4
 class GdHyper(_c.Structure):
     _fields_ = [("lr", _dbl), ("factor", _dbl), ("patience", _c.c_int32), ("mode", _c.c_int32),
                 ("depth_mask", _c.c_int32), ("depth_tau", _c.c_float), ("depth_h", _c.c_int32), ("depth_w", _c.c_int32),
-                ("depth_stride", _c.c_int32), ("images", _c.c_int32)]
+                ("depth_stride", _c.c_int32), ("fuse", _c.c_int32), ("images", _c.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/piccolo_hip.h declares
@@ -44,7 +44,7 @@ SIGNATURES = {
     "pcl_pano_pack_f16": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "pcl_loss_workspace_bytes": (_sz, [_i64, _int]),
     "pcl_sampling_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "pcl_loss_depth_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
+    "pcl_loss_depth_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int, _int]),
     "pcl_sampling_loss_depth": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _int, _int, _int, _int, _c.c_float, _int, _vp, _vp, _sz, _vp]),
     "pcl_depth_default": (_int, [_i64, _int, _int, _int, _c.POINTER(_int), _c.POINTER(_int), _c.POINTER(_c.c_float), _c.POINTER(_int)]),
     "pcl_gd_state_bytes": (_sz, [_int]),

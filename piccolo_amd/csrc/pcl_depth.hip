@@ -374,18 +374,12 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u32x4_kernel(pcl_i4* p, in
     for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = w;
 }
 
-static int pcl_depth_env(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // bytes of B z-buffers (a whole number of 16-byte words: the fill stores 16 bytes per lane)
 size_t pcl_depth_zbuf_bytes(int B, int Hd, int Wd) { return (((size_t)B * (size_t)Hd * (size_t)Wd * sizeof(uint32_t)) + 15) & ~(size_t)15; }
 
 static int pcl_depth_check(int64_t n, int B, const PclDepthGrid& g)
 {
-    if (n <= 0 || n > PCL_MAX_POINTS || B <= 0 || g.Hd < 2 || g.Wd < 2) return PCL_EINVAL;
+    if (n <= 0 || n > PCL_MAX_POINTS || B <= 0 || g.Hd < 2 || g.Wd < 2 || g.Hd >= (1 << 24) || g.Wd >= (1 << 24)) return PCL_EINVAL;
     if ((int64_t)B * g.Hd * g.Wd * 4 >= ((int64_t)1 << 32)) return PCL_EINVAL;         // the loss kernel's 32-bit buffer descriptor
     return 0;
 }
@@ -416,7 +410,7 @@ int pcl_launch_zbuffers(const float* cloud, int64_t n, const PclPoseRec* poses, 
     // window 48 x 128 + second window 195 us, without it 208, 64 x 128 206-209, 32 x 128 216, 64 x 64 225, 512-thread blocks 206,
     // 2048 samples per block 226; cache 32 slots / 2048 samples 237, 64 / 4096 247; the first form (mean-centred 32 x 64 window,
     // lane-major samples) 229.
-    static const int form_env = pcl_depth_env("PCL_ZFORM", 0), second_env = pcl_depth_env("PCL_ZSECOND", 1);
+    static const int form_env = PCL_KNOB(ZFORM, 0), second_env = PCL_KNOB(ZSECOND, 1);
     const bool dense = (double)a.nz >= 2.0 * (double)g.Hd * (double)g.Wd;
     int form = form_env >= 1 && form_env <= 3 ? form_env : (g.Wd >= 128 ? 2 : 1);
     if (form == 2 && g.Wd < 128) form = 1;
@@ -458,7 +452,7 @@ extern "C" int pcl_depth_default(int64_t n, int H, int W, int stride_in, int* de
     if (stride == 0) {
         stride = 1;
         for (int c = 2; c <= 4; c *= 2)
-            if (pcl_depth_grid_h(n / c) >= 128) stride = c;
+            if (pcl_depth_grid_h((n + c - 1) / c) >= 128) stride = c;      // (the sample count the grid below is sized from)
     }
     int hd = pcl_depth_grid_h((n + stride - 1) / stride);
     int wd = 2 * hd;

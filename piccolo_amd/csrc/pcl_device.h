@@ -7,6 +7,22 @@
 
 #include "../../include/piccolo_hip.h"
 
+// Experiment knobs.  The SHIPPED library reads no environment variable: every A/B switch of the measured-and-rejected log
+// (profiles/EXPERIMENTS.md) is PCL_KNOB(NAME, default), which is the default — a compile-time constant — unless the library is built
+// with -DPCL_EXPERIMENTS (piccolo_amd/build.py build_experiments(): lib/libpiccolo_hip_exp.so, what tools/ load through PCL_SO); only
+// that build reads PCL_<NAME> from the environment.  `strings libpiccolo_hip.so | grep -c '^PCL_'` is 0 (tests/test_abi.py).
+#ifdef PCL_EXPERIMENTS
+#include <stdlib.h>
+static inline int pcl_knob_read(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+#define PCL_KNOB(NAME, dflt) pcl_knob_read("PCL_" #NAME, (dflt))
+#else
+#define PCL_KNOB(NAME, dflt) (dflt)
+#endif
+
 #define PCL_WAVE 64
 #define PCL_BLOCK 256
 #define PCL_NACC 8  // per-pose accumulators: sum ||d||, count, sum g (3), sum p x g (3)

@@ -105,17 +105,20 @@ static int gd_depth_grid(int64_t n, int H, int W, int depth_h, int depth_w, floa
         if (rc) return rc;
     } else if (st == 0) st = 1;
     if (stride) *stride = st;
-    if (depth_h < 2 || depth_w < 2 || (int64_t)depth_h * depth_w > ((int64_t)1 << 28)) return PCL_EINVAL;
+    // (each side below 2^24: the in-kernel lookup addresses its cell with a 24-bit multiply, pcl_sample_device.h)
+    if (depth_h < 2 || depth_w < 2 || depth_h >= (1 << 24) || depth_w >= (1 << 24) || (int64_t)depth_h * depth_w > ((int64_t)1 << 28)) return PCL_EINVAL;
     *g = pcl_make_depth_grid(depth_h, depth_w, tau);
     return 0;
 }
 
 static size_t gd_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" size_t pcl_loss_depth_workspace_bytes(int64_t n, int B, int H, int W, int depth_h, int depth_w)
+// (the default grid follows the occluder stride — 1M points: 144 x 288 at the default stride 2, 200 x 400 at stride 1 — so the size query
+//  takes the stride the call will be given: ADVICE r05, a 0 x 0 grid with an explicit stride overflowed a workspace sized without it)
+extern "C" size_t pcl_loss_depth_workspace_bytes(int64_t n, int B, int H, int W, int depth_h, int depth_w, int depth_stride)
 {
     PclDepthGrid g;
-    if (n <= 0 || B <= 0 || gd_depth_grid(n, H, W, depth_h, depth_w, 0.f, 0, &g, nullptr)) return 0;
+    if (n <= 0 || B <= 0 || gd_depth_grid(n, H, W, depth_h, depth_w, 0.f, depth_stride, &g, nullptr)) return 0;
     return gd_align(pcl_loss_workspace_bytes(n, B)) + pcl_depth_zbuf_bytes(B, g.Hd, g.Wd);
 }
 
@@ -131,7 +134,8 @@ extern "C" int pcl_sampling_loss_depth(const float* cloud, int64_t n, const void
     int zstride = 1;
     int rc = gd_depth_grid(n, H, W, depth_h, depth_w, tau, depth_stride, &look.grid, &zstride);
     if (rc) return rc;
-    if (workspace_bytes < pcl_loss_depth_workspace_bytes(n, B, H, W, depth_h, depth_w)) return PCL_EWORKSPACE;
+    // sized from the grid this call RESOLVED (not from a second resolution of the arguments)
+    if (workspace_bytes < gd_align(pcl_loss_workspace_bytes(n, B)) + pcl_depth_zbuf_bytes(B, look.grid.Hd, look.grid.Wd)) return PCL_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     PclPoseRec* recs = (PclPoseRec*)workspace;
     float* partials = (float*)((char*)workspace + (size_t)B * sizeof(PclPoseRec));
@@ -290,10 +294,12 @@ extern "C" int pcl_timer_read(void* timer, double* total_ms_host, int* launches_
     return 0;
 }
 
-static int gd_fuse_limit()
+// largest grid that runs ONE launch per iteration: every block resident at once (256 CUs x 4 resident 256-thread blocks);
+// pcl_gd_hyper.fuse < 0: never (the two-launch form, bit-identical: what the parity tests compare the fused form with)
+static int gd_fuse_limit(const pcl_gd_hyper* hyper_host)
 {
-    const char* fuse_env = getenv("PCL_GD_FUSE_BLOCKS");          // (read per call: tests run both forms in one process)
-    return fuse_env && *fuse_env ? atoi(fuse_env) : 1024;
+    if (hyper_host && hyper_host->fuse < 0) return 0;
+    return PCL_KNOB(GD_FUSE_BLOCKS, 1024);                          // (experiments build: read per call)
 }
 
 extern "C" int pcl_gd_plan_hyper(int64_t n, int B, const pcl_gd_hyper* hyper_host, int* nchunks_host, int* poses_per_block_host, int* fused_host)
@@ -303,7 +309,7 @@ extern "C" int pcl_gd_plan_hyper(int64_t n, int B, const pcl_gd_hyper* hyper_hos
     if (poses_per_block_host) *poses_per_block_host = pcl_plan_G(n, B);
     // (the depth-masked loss pass reads a byte mask the fused prologue knows nothing about: pcl_gd_run keeps two launches there)
     const bool depth = hyper_host && hyper_host->depth_mask;
-    if (fused_host) *fused_host = (!depth && pcl_plan_nblocks(n, B) <= gd_fuse_limit()) ? 1 : 0;
+    if (fused_host) *fused_host = (!depth && pcl_plan_nblocks(n, B) <= gd_fuse_limit(hyper_host)) ? 1 : 0;
     return 0;
 }
 
@@ -370,24 +376,24 @@ extern "C" int pcl_gd_run(const float* cloud, int64_t n, const void* pano, int p
         look.zclear_vec4 = (int64_t)(pcl_depth_zbuf_bytes(B, look.grid.Hd, look.grid.Wd) / 16);
     }
     const bool depth_on = zbuf2[0] != nullptr;
-    static const int pingpong_env = getenv("PCL_ZPINGPONG") ? atoi(getenv("PCL_ZPINGPONG")) : 1;      // 0: a fill launch per iteration (A/B)
+    static const int pingpong_env = PCL_KNOB(ZPINGPONG, 1);      // 0: a fill launch per iteration (A/B)
     const int nchunks = pcl_plan_nchunks(n, B);
     // odd iterations walk every XCD's chunks backwards: the first blocks of a launch then read the chunks the previous launch
     // finished with, still in that XCD's L2 (PCL_FLIP=0 turns it off; +0.3 % at cfg 2 in two A/B alternations on one box —
     // the first round of a launch stays 6 us slower than the later ones, so cold L2 is not what makes it slow)
-    static const int flip_env = getenv("PCL_FLIP") ? atoi(getenv("PCL_FLIP")) : 1;
+    static const int flip_env = PCL_KNOB(FLIP, 1);
     // ONE launch per iteration for launches whose blocks are all resident at once (the reference's shipped 167k-point /
     // 6-candidate shape, cfg 1): there an iteration is two dependent launches of a few microseconds, and the 5 us the epilogue
     // launch costs are pure dispatch.  The loss launch of iteration k + 1 finishes iteration k in the prologue of every block
     // (PclFuseArgs) — no inter-block synchronisation, the kernel boundary is the only one; the last iteration is finished by
     // the stand-alone epilogue.  Same arithmetic in the same order: results are bit-identical to the two-launch form
-    // (PCL_GD_FUSE_BLOCKS: largest grid that takes this path, 0 = never).
+    // (pcl_gd_hyper.fuse < 0: never — the form the parity tests compare this one with).
     // several panoramas in the launch AND a cloud small enough to live in every XCD's L2 next to a texture (6 MB: the reference's
     // shipped 167k points): the XCDs split the pose groups — the images — instead of the chunks (pcl_launch_loss).  Large clouds keep
     // the chunk mapping: measured at 1M points, 8 images per launch +0.3 % (3 523 -> 3 533), 5 images per launch (the driver's shape:
     // 10 groups per XCD straddling the images, every XCD walking the whole 24 MB cloud) -1.5 % (3 533 -> 3 479).
     const int xcd_bit = hyper_host->images > 1 && n * 24 <= ((int64_t)6 << 20) ? 2 : 0;
-    const int fuse_blocks = gd_fuse_limit();
+    const int fuse_blocks = gd_fuse_limit(hyper_host);
     const bool fused = !depth_on && pcl_plan_nblocks(n, B) <= fuse_blocks;
     const int G = pcl_plan_G(n, B);
     auto epilogue = [&](int it, int copy_in, float* partials) {

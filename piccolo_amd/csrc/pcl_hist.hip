@@ -708,12 +708,6 @@ __global__ void pcl_hist_pose_setup_kernel(const float* __restrict__ trans, cons
 
 static size_t hist_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int pcl_hist_env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // can the tile-binned render be used at all for this cloud / panorama (16-bit pixel fields, 28-bit slots, <= 4096 tiles)?
 static bool hist_binned_ok(int64_t n, int H, int W)
 {
@@ -801,12 +795,11 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
     hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, nimages), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
                        cloud, stride, imgs, cpi, H, W, nsh, nsw, ghist_q, qmask);
     hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, nimages), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj, cpi);
-    // Tile-binned path when the caller sized the workspace for it.  PCL_HIST_SPLAT=1 forces the z-buffer path (tests compare
-    // the two bit for bit).
-    const int force_splat = pcl_hist_env_int("PCL_HIST_SPLAT", 0);      // (read per call: a handful of calls per image)
+    // Tile-binned path when the caller sized the workspace for it (pcl_hist_trim_workspace_bytes_n); a caller that passes the smaller
+    // pcl_hist_trim_workspace_bytes gets the z-buffer splat — how the tests compare the two bit for bit.
     const int ntx = (W + PCL_TS - 1) / PCL_TS, nty = (H + PCL_TS - 1) / PCL_TS, nt = ntx * nty;
     const int64_t cap = 4 * n;
-    if (!force_splat && roomy && hist_binned_ok(n, H, W)) {
+    if (roomy && hist_binned_ok(n, H, W)) {
         PclBinArgs b;
         b.cloud = cloud; b.n = n; b.stride = stride; b.poses = recs; b.H = H; b.W = W; b.ntx = ntx; b.nt = nt;
         // layout of the render area: [ncand] x heads[nt] (16 B), [ncand] x stat[nt] (8 B), [ncand] x runs[nt][nb] (8 B), [ncand] x lists[3][cap]
@@ -818,7 +811,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.cap = cap;
         // margins of the fast projection's certificate: 1.5e-6 x the image size (three times the error budget in the kernel's comment),
         // at least 1e-3 pixel; PCL_BIN_EXACT=1: the reference formula for every point (A/B, and the cross-check of the certificate)
-        const bool exact_env = pcl_hist_env_int("PCL_BIN_EXACT", 0) != 0;
+        const bool exact_env = PCL_KNOB(BIN_EXACT, 0) != 0;
         b.fast_margin_x = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)W);
         b.fast_margin_y = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)H);
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
@@ -831,12 +824,12 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         // pre-dedup pays where pixels hold several points: measured (round 4, two-pass form) at 1M points on 2048 x 1024 (0.5 points per
         // pixel) resolve 613 -> 498, scatter 491 -> 437, count 283 -> 355 us per 64 candidates (-7 % for the stage); at 167k points (0.08
         // per pixel) nothing is dropped and the compares cost 9 us per 50 candidates — hence the density gate.  PCL_BIN_DEDUP=0 / 1 forces.
-        const int dedup_env = pcl_hist_env_int("PCL_BIN_DEDUP", -1);
+        const int dedup_env = PCL_KNOB(BIN_DEDUP, -1);
         const bool dedup = dedup_env >= 0 ? dedup_env != 0 : 4 * n >= (int64_t)H * W;
         if (dedup) hipLaunchKernelGGL((pcl_bin_kernel<true>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
         else hipLaunchKernelGGL((pcl_bin_kernel<false>), pgrid, dim3(PCL_BLOCK), (size_t)2 * nt * sizeof(int), s, b);
         hipLaunchKernelGGL(pcl_bin_rank_kernel, dim3(ncand, (nt + 63) / 64), dim3(PCL_BLOCK), (size_t)(((nt + 3) & ~3) + PCL_BLOCK) * sizeof(int), s, b);
-        const int rt_env = pcl_hist_env_int("PCL_RESOLVE_THREADS", 0);
+        const int rt_env = PCL_KNOB(RESOLVE_THREADS, 0);
         const int rt = rt_env == 256 ? 256 : 1024;      // measured: 256 threads LOSE at both shapes (0.434 -> 0.489 ms at 167k x 50, 1.35 -> 1.53 at 1M x 64)
         if (rt == 1024) hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<1024>, dim3(ncand, nt), dim3(1024), 0, s, b, qmask, codes, cpi, nsh, nsw, ghist_c);
         else hipLaunchKernelGGL(pcl_tile_resolve_hist_kernel<256>, dim3(ncand, nt), dim3(256), 0, s, b, qmask, codes, cpi, nsh, nsw, ghist_c);

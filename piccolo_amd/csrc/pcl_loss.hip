@@ -316,12 +316,8 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_loss_fused_kernel(PclLossArgs a
 // ------------------------------------------------------------------------------------------------------------
 // launch planning (shared with the GD loop)
 
-// tuning knobs for tools/kbench.py (read once per process): PCL_G = poses per block (1/2/4), PCL_BLOCKS = target grid size
-static int pcl_env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
+// tuning knobs for tools/kbench.py (experiments build only, read once per process): PCL_G = poses per block (1/2/4), PCL_BLOCKS =
+// target grid size
 
 struct PclPlan {
     int G, ngroups, nchunks;
@@ -331,7 +327,7 @@ struct PclPlan {
 
 static PclPlan pcl_plan(int64_t n, int B)
 {
-    static const int g_env = pcl_env_int("PCL_G", 0), blocks_env = pcl_env_int("PCL_BLOCKS", 4096);
+    static const int g_env = PCL_KNOB(G, 0), blocks_env = PCL_KNOB(BLOCKS, 4096);
     PclPlan p;
     // poses per block: 2 measured best at cfg2 (4: 146 VGPRs -> 3 waves/SIMD; 1: point loads not amortised)
     p.G = (B % 2 == 0) ? 2 : 1;
@@ -367,7 +363,7 @@ static PclPlan pcl_plan(int64_t n, int B)
     // are resident at once (the shipped 167k-point / 6-candidate shape: 984 one-step blocks): nothing to balance there, and
     // with its chunks side by side an XCD touches an eighth of the panorama instead of all of it (loss kernel 9.5 vs 10.8 us).
     // Otherwise the largest divisor of the XCD's chunk count not above the target.
-    static const int runs_env = pcl_env_int("PCL_XCD_RUNS", 0);
+    static const int runs_env = PCL_KNOB(XCD_RUNS, 0);
     int cpx = p.nchunks / 8, runs = runs_env < 1 || runs_env > cpx ? cpx : runs_env;
     if (runs_env < 1 && (int64_t)p.nchunks * p.ngroups <= 1024) runs = 1;       // 256 CUs x 4 resident 256-thread blocks
     while (cpx % runs) runs--;
@@ -390,7 +386,7 @@ int pcl_plan_G(int64_t n, int B) { return pcl_plan(n, B).G; }
 void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int* steps_base, int* steps_rem)
 {
     PclPlan p = pcl_plan(n, 2 * ngroups);
-    static const int chunks_env = pcl_env_int("PCL_TRIM_CHUNKS", 0);          // experiments
+    static const int chunks_env = PCL_KNOB(TRIM_CHUNKS, 0);          // experiments
     // Hundreds of slots share every chunk, so the plan above settles on its minimum of 64 chunks whatever the cloud — and a chunk of a
     // large cloud is then a large piece of the room: at 4M points on 4096 x 2048 (62k points per chunk) the 1800-pose launch took 16.3 ms,
     // with 20k points per chunk 13.3, with 8k 13.0; 10M points: 30.1 / 27.9 (20k) / 28.2 (10k) ms; at 2048 x 1024 the count hardly matters
@@ -403,7 +399,7 @@ void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int
         int64_t steps = (n + PCL_STEP - 1) / PCL_STEP, want = (((chunks_env >= 8 ? chunks_env : auto_chunks) + 7) / 8) * 8;
         if (want > steps) want = ((steps + 7) / 8) * 8;
         p.nchunks = (int)want; p.steps_base = (int)(steps / want); p.steps_rem = (int)(steps % want);
-        static const int runs_env = pcl_env_int("PCL_TRIM_RUNS", 0);
+        static const int runs_env = PCL_KNOB(TRIM_RUNS, 0);
         int cpx = p.nchunks / 8, runs = runs_env < 1 || runs_env > cpx ? cpx : runs_env;
         while (cpx % runs) runs--;
         p.seg_len = cpx / runs;
@@ -475,7 +471,7 @@ int pcl_launch_loss(const float* cloud, int64_t n, const void* pano, int pano_fo
     // candidates of 8 images 64.0 -> 49.8 us (poses all over the room) / 51.3 -> 41.7 us (near the ground truth), 1M points x 256
     // candidates of 8 images 797 -> 761 us.  The partial sums per (group, chunk) are the same: results unchanged bit for bit.
     // PCL_XCD_GROUPS=0 / 1 forces the mapping off / on (A/B).
-    static const int xg_env = pcl_env_int("PCL_XCD_GROUPS", -1);
+    static const int xg_env = PCL_KNOB(XCD_GROUPS, -1);
     a.xcd_groups = ((flip & 2) != 0 || xg_env == 1) && xg_env != 0 && p.ngroups % 8 == 0 ? 1 : 0;
     int nblk = p.nchunks * p.ngroups;
     const int vis = depth ? 2 : visible != nullptr ? 1 : 0;

@@ -510,8 +510,7 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
     {
         // measured for 8 images per launch (tools/trim8.py, rows bit-identical): 167k points 0.776 -> 0.747 ms per image, 1M points
         // 3.094 -> 3.056.  PCL_TRIM_XCD_IMAGES=0 / 1 forces the mapping off / on (A/B).
-        const char* xe = getenv("PCL_TRIM_XCD_IMAGES");
-        a.xcd_images = nimages % 8 == 0 && (xe ? atoi(xe) != 0 : true) ? 1 : 0;
+        a.xcd_images = nimages % 8 == 0 && PCL_KNOB(TRIM_XCD_IMAGES, 1) != 0 ? 1 : 0;
     }
     a.dims = pcl_make_dims(H, W, pano_format == PCL_PANO_U8P || pano_format == PCL_PANO_U8V ? PCL_PANO_U8 : pano_format);       // (the same levels, the same constants)
     a.poses = recs; a.hdr = hdr; a.groups = grs; a.K = K; a.nslots = nslots; a.partials = partials;

@@ -21,7 +21,6 @@ device (csrc/pcl_gd.hip) without a host round trip per iteration.  Differences a
     omniloc returns the frame list that code means to build (query image over the cloud rendered at the current pose,
     per iteration) as 4th element.
 """
-import os
 import weakref
 from collections import OrderedDict
 
@@ -123,15 +122,15 @@ def packed_pano(img, many_poses=False, n_points=None):
     caches): the two stages share a packing only for dense clouds' trim ('u8') and a sparse cloud's refinement ('u8').  Images that
     are not k/255 get float4 texels either way."""
     rgba8 = many_poses or (n_points is not None and ops.refine_texels(n_points, img.shape[0], img.shape[1]) == "u8")
-    if os.environ.get("PCL_PANO_FMT") in ("f16", "f32") and not many_poses:      # experiments: force the refinement's format
+    if ops.EXPERIMENT.pano_fmt in ("f16", "f32") and not many_poses:             # experiments: force the refinement's format
         rgba8 = False
     if not rgba8:
         return _cached("pano", (img,), lambda: ops.Pano(img))
     # the trim launch picks its own layout by point density (ops.trim_texels: rows interleaved in pairs / plain rows / vertical pairs);
     # nothing else reads the paired layouts
     fmt = ops.trim_texels(n_points, img.shape[0], img.shape[1]) if many_poses and n_points is not None else "u8"
-    if os.environ.get("PCL_TRIM_FMT") in ("u8", "u8p", "u8v") and many_poses:     # experiments
-        fmt = os.environ["PCL_TRIM_FMT"]
+    if ops.EXPERIMENT.trim_fmt in ("u8", "u8p", "u8v") and many_poses:            # experiments
+        fmt = ops.EXPERIMENT.trim_fmt
 
     def make():
         try:
@@ -176,15 +175,16 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
     hyper = (float(_cfg(cfg, "lr", 0.1)), int(_cfg(cfg, "patience", 5)), float(_cfg(cfg, "factor", 0.9)), bool(batch_mode), depth,
              None if d_tau is None else float(d_tau), None if d_res is None else (int(d_res[0]), int(d_res[1])), None if d_st is None else int(d_st))
     use_graph = _cfg(cfg, "gd_graph", None)
-    if use_graph is None and os.environ.get("PCL_GD_GRAPH") in ("0", "1"):          # experiments
-        use_graph = os.environ["PCL_GD_GRAPH"] == "1"
+    if use_graph is None and ops.EXPERIMENT.gd_graph is not None:                   # experiments
+        use_graph = bool(ops.EXPERIMENT.gd_graph)
+    fuse = None if _cfg(cfg, "gd_fuse", True) else False       # (cfg gd_fuse = False: two launches per iteration, bit-identical)
     if use_graph is None:
         use_graph = cloud.n * B <= GRAPH_POINT_POSES
     use_graph = bool(use_graph) and vis_hook is None and not depth
 
     def make(c=cloud, bx=box):
         return ops.GradientDescent(c, p0, trans, rot, bx, lr=hyper[0], patience=hyper[1], factor=hyper[2], batch_mode=hyper[3],
-                                   depth_mask=hyper[4], depth_tau=hyper[5], depth_res=hyper[6], depth_stride=hyper[7])
+                                   depth_mask=hyper[4], depth_tau=hyper[5], depth_res=hyper[6], depth_stride=hyper[7], fuse=fuse)
     if not use_graph:
         gd = make()                                        # (fresh buffers: nothing worth keeping for a long eager chain)
     else:
@@ -197,8 +197,8 @@ def _refine(xyz, rgb, panos, trans, rot, box, cfg, batch_mode, vis_hook=None):
             g._cloud_src = weakref.ref(cloud)                # the copy just made IS this cloud: nothing to copy on first use
             g._box_src, g._fresh = box, True
             return g
-        # (the fuse limit is read by pcl_gd_run per call but frozen into a captured graph: part of the key)
-        gd = _cached("gd", (xyz,), make_private, sub=(B, len(panos), p0.H, p0.W, p0.fmt, os.environ.get("PCL_GD_FUSE_BLOCKS")) + hyper)
+        # (one or two launches per iteration is frozen into a captured graph: part of the key)
+        gd = _cached("gd", (xyz,), make_private, sub=(B, len(panos), p0.H, p0.W, p0.fmt, fuse) + hyper)
         fresh, gd._fresh = gd._fresh, False                  # (a new engine was initialised with these very poses)
         if gd._cloud_src() is not cloud:                     # weak: the engine must not keep packed clouds of past images alive
             gd.cloud.data.copy_(cloud.data)

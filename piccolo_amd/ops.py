@@ -5,11 +5,27 @@ Inputs may live on the CPU (the reference's harness hands over whatever `device`
 they are uploaded to cuda:0.  Without a GPU or without the library every call raises — there is no fallback.
 """
 import ctypes
-import os
 
 import torch
 
 from . import _lib
+
+
+class _Experiment:
+    """A/B switches of the measured-and-rejected log (profiles/EXPERIMENTS.md).  The product reads NO environment variable: these are
+    plain attributes, all None / False by default, set by a tool or a test in its own process (tools/_knobs.py maps the old PCL_*
+    variables onto them for the sweep scripts).
+      pano_fmt      "f16" | "f32": what Pano(fmt="auto") tries first / forces for the refinement's panorama
+      trim_fmt      "u8" | "u8p" | "u8v": the trim launch's texel layout instead of ops.trim_texels' choice
+      gd_graph      True | False: hipGraph replay of the refinement chain on / off whatever the problem size
+      verify_levels True: ignore synth.mark_levels' tag (the device-side k/255 check is read back as for any tensor)"""
+    pano_fmt = None
+    trim_fmt = None
+    gd_graph = None
+    verify_levels = False
+
+
+EXPERIMENT = _Experiment()
 
 F32 = torch.float32
 
@@ -102,8 +118,8 @@ class Pano:
         if fmt not in ("auto", "f16", "u8", "u8p", "u8v", "f32"):
             raise ValueError("unknown texel format %r" % (fmt,))
         prefer = "f16"
-        if fmt == "auto":                                     # experiments: PCL_PANO_FMT = what "auto" tries first
-            prefer = os.environ.get("PCL_PANO_FMT", "f16")
+        if fmt == "auto":                                     # (experiments: what "auto" tries first)
+            prefer = EXPERIMENT.pano_fmt or "f16"
             if prefer == "f32":
                 fmt = "f32"
         if fmt != "f32":
@@ -166,10 +182,10 @@ def trim_texels(n, H, W):
 
 
 def _known_levels(img):
-    """True for a tensor tagged by synth.mark_levels (every value exactly k/255 by construction); PCL_VERIFY_LEVELS=1 ignores
+    """True for a tensor tagged by synth.mark_levels (every value exactly k/255 by construction); EXPERIMENT.verify_levels ignores
     the tag (the device-side check is then read back as for any other tensor)."""
     tag = getattr(img, "_pcl_levels", None)
-    return tag is not None and torch.is_tensor(img) and tag == img._version and os.environ.get("PCL_VERIFY_LEVELS") != "1"
+    return tag is not None and torch.is_tensor(img) and tag == img._version and not EXPERIMENT.verify_levels
 
 
 def default_depth(n, H, W, stride=0):
@@ -219,7 +235,7 @@ def sampling_loss(cloud, pano, trans, rot, with_grad=True, visible=None, depth=N
             raise ValueError("sampling_loss: pass either a byte mask (visible) or depth, not both")
         d = depth if isinstance(depth, dict) else {}
         dh, dw, tau, st = _depth_args(cloud.n, pano.H, pano.W, d.get("depth_res"), d.get("depth_tau"), d.get("depth_stride"))
-        ws_bytes = lib.pcl_loss_depth_workspace_bytes(cloud.n, B, pano.H, pano.W, dh, dw)
+        ws_bytes = lib.pcl_loss_depth_workspace_bytes(cloud.n, B, pano.H, pano.W, dh, dw, st)
         if ws_bytes == 0:
             raise _lib.PiccoloHipError("pcl_loss_depth_workspace_bytes: invalid depth grid %dx%d" % (dh, dw))
         ws = _bytes(ws_bytes)
@@ -335,18 +351,23 @@ def select_poses(values, n_keep, trans, rot, largest=False, rot_per_trans=0, ret
 SELECT_MAX_KEEP = 1024      # pcl_select_poses: winners per problem (include/piccolo_hip.h)
 
 
-def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False):
+def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64, return_parts=False, splat=False):
     """Histogram-intersection score of every candidate pose (utils.py:510-588): (K,) GPU tensor, higher is better.
     `cloud` is a packed Cloud.  Candidates are processed `batch` at a time.  Workspace per candidate: the point lists of the
     tile-binned render (48 bytes per point in the worst case, plus the tiles' run tables — 2 bytes per point for a 2048 x 1024 panorama: 3.2 GB for 64
     candidates at 1M points; HBM is there to be used),
     or, where that path does not apply (more than 4096 image tiles, ...) or does not fit, H * W * 8 bytes for the z-buffer of the
     splat path.  If the allocation fails the batch is halved, and the last resort is the splat path's small workspace.
-    return_parts: (scores, inter, nproj, nimg)."""
+    return_parts: (scores, inter, nproj, nimg).  splat=True: the z-buffer splat path on purpose (its small workspace selects it in
+    pcl_hist_trim_scores; the tests compare the two renderers bit for bit)."""
     lib = _lib.load()
     img = _dev(img)
     trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
     K, (H, W) = int(trans.shape[0]), (int(img.shape[0]), int(img.shape[1]))
+    if splat:
+        size_of = lambda b: lib.pcl_hist_trim_workspace_bytes(b, H, W, num_split_h, num_split_w)          # noqa: E731
+    else:
+        size_of = lambda b: lib.pcl_hist_trim_workspace_bytes_n(cloud.n, b, H, W, num_split_h, num_split_w)  # noqa: E731
     nblk = (num_split_h - 2) * num_split_w
     inter = torch.empty(K, nblk, dtype=F32, device=img.device)
     nproj = torch.empty(K, nblk, dtype=torch.int32, device=img.device)
@@ -354,13 +375,13 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
     # one batch for the 64 survivors of the loss trim at 1M points (four batches of 16: 2.0 instead of 1.7 ms; 0.8 instead of
     # 0.5 ms at 167k points); a batch is kept within ~8 GB (10M points: 16 candidates at a time).
     # pcl_hist_trim_workspace_bytes_n is the binned path's size where that path will be taken, the splat path's otherwise.
-    per_cand = max(lib.pcl_hist_trim_workspace_bytes_n(cloud.n, 1, H, W, num_split_h, num_split_w), 1)
+    per_cand = max(size_of(1), 1)
     batch = max(1, min(batch, K, int(HIST_BATCH_BYTES // per_cand)))
-    if lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w) == 0:
+    if size_of(batch) == 0:
         raise ValueError("hist_trim_scores: need num_split_h >= 3 and blocks of at least one pixel")
     ws = None
     while ws is None:
-        nws = lib.pcl_hist_trim_workspace_bytes_n(cloud.n, batch, H, W, num_split_h, num_split_w)
+        nws = size_of(batch)
         try:
             ws = _bytes(nws)
         except torch.cuda.OutOfMemoryError:
@@ -385,8 +406,8 @@ def hist_trim_scores(img, cloud, trans, rot, num_split_h, num_split_w, batch=64,
 
 
 HIST_MAX_IMAGES = 32       # pcl_hist_trim_scores_images: query images per call
-# bytes of point lists one histogram-trim call may hold (experiments: PCL_HIST_BATCH_BYTES)
-HIST_BATCH_BYTES = float(os.environ.get("PCL_HIST_BATCH_BYTES", "8e9"))
+# bytes of point lists one histogram-trim call may hold
+HIST_BATCH_BYTES = 8e9
 
 
 def hist_trim_scores_images(imgs, cloud, trans, rot, num_split_h, num_split_w):
@@ -540,7 +561,9 @@ class GradientDescent:
     """On-device GD refinement of B candidates (Adam + ReduceLROnPlateau + clamp), pcl_gd_* of the C ABI."""
 
     def __init__(self, cloud, pano, trans, rot, box, lr=0.1, patience=5, factor=0.9, batch_mode=True, depth_mask=False,
-                 depth_tau=None, depth_res=None, depth_stride=None):
+                 depth_tau=None, depth_res=None, depth_stride=None, fuse=None):
+        """fuse None: pcl_gd_plan's rule (one launch per iteration for launches whose blocks are all resident); False: always the
+        two-launch form (bit-identical; tests and measurements)."""
         lib = _lib.load()
         self.cloud, self.pano = cloud, pano
         trans, rot = _dev(trans).reshape(-1, 3), _dev(rot).reshape(-1, 3)
@@ -548,7 +571,7 @@ class GradientDescent:
         self.box = _dev(box).reshape(6)
         dh, dw, tau, st = _depth_args(cloud.n, pano.H, pano.W, depth_res, depth_tau, depth_stride) if depth_mask else (0, 0, 0.0, 0)
         self.hyper = _lib.GdHyper(float(lr), float(factor), int(patience), _lib.GD_BATCH if batch_mode else _lib.GD_SEQUENTIAL,
-                                  1 if depth_mask else 0, float(tau), int(dh), int(dw), int(st), 0)
+                                  1 if depth_mask else 0, float(tau), int(dh), int(dw), int(st), -1 if fuse is False else 0, 0)
         self.state = _bytes(lib.pcl_gd_state_bytes(self.B))
         self.ws_bytes = lib.pcl_gd_workspace_bytes(cloud.n, self.B, pano.H, pano.W, ctypes.byref(self.hyper))
         if self.ws_bytes == 0:

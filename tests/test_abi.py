@@ -174,7 +174,56 @@ def test_depth_default_grid_and_tolerance_host_only():
     assert lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper)) - plain == 2 * 32 * 1024 * 2048 * 4
     hyper.depth_h, hyper.depth_w = 200, 0                           # half a grid: invalid
     assert lib.pcl_gd_workspace_bytes(1_000_000, 32, 1024, 2048, ctypes.byref(hyper)) == 0
-    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 0, 0) > lib.pcl_loss_workspace_bytes(1_000_000, 32)
+    plain_loss = lib.pcl_loss_workspace_bytes(1_000_000, 32)
+    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 0, 0, 0) > plain_loss
+    # the DEFAULT grid follows the occluder stride, so the size query takes the stride the call will be given —
+    # 0 x 0 with stride 1 is 200 x 400 cells per pose, not the 144 x 288 of the default stride 2
+    align = lambda v: (v + 255) & ~255                                # noqa: E731
+    for stride, (dh, dw) in ((0, (144, 288)), (2, (144, 288)), (1, (200, 400)), (4, dflt(1_000_000, 1024, 2048, 4)[:2])):
+        got = lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 0, 0, stride)
+        assert got == align(plain_loss) + 32 * dh * dw * 4, (stride, got)
+    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 300, 600, 1) == align(plain_loss) + 32 * 300 * 600 * 4
+    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 32, 1024, 2048, 0, 0, 65) == 0                    # stride out of range
+    assert lib.pcl_loss_depth_workspace_bytes(1_000_000, 1, 1024, 2048, 2, 1 << 24, 1) == 0                # a side of 2^24 cells: rejected
+    hyper.depth_h, hyper.depth_w = 2, 1 << 24
+    assert lib.pcl_gd_workspace_bytes(1_000_000, 1, 1024, 2048, ctypes.byref(hyper)) == 0
+
+
+def test_shipped_library_reads_no_environment_variable(lib):
+    """seventeen getenv knobs lived in the product library; `PCL_G` / `PCL_BLOCKS` changed the chunking — hence
+    the rounding of every loss — and the workspace sizes of a C ABI that otherwise has no hidden state.  They now exist only in the
+    EXPERIMENTS build (-DPCL_EXPERIMENTS, lib/libpiccolo_hip_exp.so): the shipped library holds no PCL_* string,
+    calls no getenv of its own, and its size queries ignore the environment."""
+    from piccolo_amd import _lib, build
+    blob = subprocess.check_output(["strings", _lib.so_path()], text=True).splitlines()
+    assert not [ln for ln in blob if ln.startswith("PCL_")], [ln for ln in blob if ln.startswith("PCL_")][:5]
+    # (the library still IMPORTS getenv: rocprim's radix-sort headers, used by pcl_pack.hip / pcl_color.hip, read their own variables;
+    #  no translation unit of csrc/ calls it outside PCL_EXPERIMENTS — checked on the sources)
+    import glob
+    for path in glob.glob(os.path.join(REPO, "piccolo_amd", "csrc", "*")):
+        text = open(path).read()
+        if "getenv" in text:
+            assert os.path.basename(path) == "pcl_device.h" and text.index("#ifdef PCL_EXPERIMENTS") < text.index("getenv") < text.index("#else"), path
+    before = (lib.pcl_loss_workspace_bytes(1_000_000, 32), lib.pcl_trim_loss_workspace_bytes(1_000_000, 75, 6))
+    knobs = dict(PCL_G="1", PCL_BLOCKS="512", PCL_XCD_RUNS="4", PCL_TRIM_CHUNKS="128", PCL_GD_FUSE_BLOCKS="0")
+    code = ("from piccolo_amd import _lib; lib = _lib.load(); "
+            "print(lib.pcl_loss_workspace_bytes(1000000, 32), lib.pcl_trim_loss_workspace_bytes(1000000, 75, 6))")
+    out = subprocess.check_output([os.sys.executable, "-c", code], env=dict(os.environ, **knobs), cwd=REPO, text=True)
+    assert tuple(int(v) for v in out.split()[-2:]) == before
+    # the experiments build is the one that listens (same sources, one more -D)
+    exp = build.build_experiments()
+    exp_strings = subprocess.check_output(["strings", exp], text=True).splitlines()
+    assert {"PCL_G", "PCL_BLOCKS", "PCL_GD_FUSE_BLOCKS"} <= set(exp_strings)
+    out = subprocess.check_output([os.sys.executable, "-c", code], env=dict(os.environ, PCL_SO=exp, **knobs), cwd=REPO, text=True)
+    assert tuple(int(v) for v in out.split()[-2:]) != before
+    # ... and nothing under piccolo_amd/ reads PCL_* from the environment except PCL_SO (which library to load) and the build's flags
+    import glob
+    hits = []
+    for path in glob.glob(os.path.join(REPO, "piccolo_amd", "*.py")):
+        for i, ln in enumerate(open(path), 1):
+            if "environ" in ln and "PCL_" in ln and "PCL_SO" not in ln and "PCL_HIPCC_FLAGS" not in ln:
+                hits.append((os.path.basename(path), i))
+    assert not hits, hits
 
 
 def test_gd_plan_reports_the_decomposition_host_only():
@@ -188,18 +237,21 @@ def test_gd_plan_reports_the_decomposition_host_only():
         c, g, f = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
         assert lib.pcl_gd_plan(n, B, ctypes.byref(c), ctypes.byref(g), ctypes.byref(f)) == 0
         return c.value, g.value, f.value
-    old = os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
-    try:
+    if True:
         c, g, f = plan(166_667, 6)
         assert g == 2 and f == 1 and c % 8 == 0 and c * 3 <= 1024            # 3 pose groups x chunks: all resident
         assert plan(100_000, 1)[1:] == (1, 1)                                # cfg 1: one pose per block, fused
         c, g, f = plan(1_000_000, 32)
         assert (c, g, f) == (256, 2, 0)                                      # cfg 2: 4096 blocks, two launches per iteration
         assert plan(1_000_000, 256)[2] == 0 and plan(10_000_000, 64)[2] == 0
-        os.environ["PCL_GD_FUSE_BLOCKS"] = "0"                               # read per call
-        assert plan(166_667, 6)[2] == 0
-    finally:
-        os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
-        if old is not None:
-            os.environ["PCL_GD_FUSE_BLOCKS"] = old
+        # pcl_gd_hyper.fuse = -1: never one launch per iteration (the form the parity tests compare the fused one with); the
+        # environment does not reach the shipped library (no getenv: test_shipped_library_reads_no_environment_variable)
+        fz = ctypes.c_int(-1)
+        hy = _lib.GdHyper(0.1, 0.8, 5, 1, 0, 0.0, 0, 0, 0, -1, 0)
+        assert lib.pcl_gd_plan_hyper(166_667, 6, ctypes.byref(hy), None, None, ctypes.byref(fz)) == 0 and fz.value == 0
+        os.environ["PCL_GD_FUSE_BLOCKS"] = "0"
+        try:
+            assert plan(166_667, 6)[2] == 1
+        finally:
+            del os.environ["PCL_GD_FUSE_BLOCKS"]
     assert lib.pcl_gd_plan(0, 6, None, None, None) == -1 and lib.pcl_gd_plan(1000, 4, None, None, None) == 0

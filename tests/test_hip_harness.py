@@ -1,5 +1,7 @@
 """GPU tests of the callers either side of the hot path: candidate generation, the two trimming
 stages of make_input, and the synthetic harness."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -672,15 +674,13 @@ def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
     """Launches whose blocks are all resident at once (the reference's shipped 167k-point / 6-candidate shape, cfg 1) run ONE
     launch per GD iteration: every block of iteration k + 1 finishes iteration k for its own poses in its prologue (same
     reduction order, chain rule, Adam, scheduler, clamp as the stand-alone epilogue kernel; the block of chunk 0 stores the
-    state), the last iteration is finished by the stand-alone epilogue.  PCL_GD_FUSE_BLOCKS=0 selects the two-launch form:
+    state), the last iteration is finished by the stand-alone epilogue.  fuse=False (pcl_gd_hyper.fuse = -1) selects the two-launch form:
     optimiser state, poses, per-iteration loss history and the caller-visible results must agree BIT FOR BIT — both modes,
     even and odd candidate counts, one candidate, per-candidate panoramas, 1 / 2 / 3 / 100 iterations, run() called in pieces."""
-    import os
     from piccolo_amd import ops, synth
     H, W = 64, 128
     cases = [(20_000, 6, True), (20_000, 5, True), (20_000, 1, False), (20_000, 4, False), (166_667, 6, True), (100_000, 1, False)]
-    old = os.environ.get("PCL_GD_FUSE_BLOCKS")
-    try:
+    if True:
         for n, B, batch_mode in cases:
             xyz, rgb = synth.box_room(n, 90 + B)
             X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()
@@ -699,18 +699,22 @@ def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
             table = [panos[b % 2] for b in range(B)]             # candidates alternate between two panoramas
             out = {}
             for mode in ("two", "fused"):
-                os.environ["PCL_GD_FUSE_BLOCKS"] = "0" if mode == "two" else "1024"
+                fuse = False if mode == "two" else None
+                fz = ctypes.c_int(-1)
+                hy = ops._lib.GdHyper(0.1, 0.8, 5, 1 if batch_mode else 0, 0, 0.0, 0, 0, 0, -1 if fuse is False else 0, 0)
+                assert ops._lib.load().pcl_gd_plan_hyper(n, B, ctypes.byref(hy), None, None, ctypes.byref(fz)) == 0
+                assert fz.value == (0 if mode == "two" else 1), (n, B, mode)        # every case here fuses by the rule
                 runs = []
                 for num_iter in (1, 2, 3, 100):
-                    gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                    gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode, fuse=fuse)
                     gd.set_panos(table)
                     hist = gd.run(num_iter, history=True)
                     runs.append((hist.clone(), gd.result().clone(), gd.state.clone()[: B * (160 + 64)]))
                 # in pieces: 2 + 1 + 4 iterations continue one another exactly like 7 in one call
-                gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                gd = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode, fuse=fuse)
                 gd.set_panos(table)
                 pieces = torch.cat([gd.run(2, history=True), gd.run(1, history=True), gd.run(4, history=True)])
-                gd7 = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode)
+                gd7 = ops.GradientDescent(cloud, panos[0], tr, ro, box, lr=0.1, patience=5, factor=0.8, batch_mode=batch_mode, fuse=fuse)
                 gd7.set_panos(table)
                 whole = gd7.run(7, history=True)
                 assert torch.equal(pieces, whole) and torch.equal(gd.result(), gd7.result()), (n, B, mode)
@@ -720,11 +724,6 @@ def test_fused_iterations_are_bit_identical_to_the_two_launch_form(oracle):
                 assert torch.equal(h2, hf), (n, B, "loss history", (h2 - hf).abs().max())
                 assert torch.equal(r2, rf), (n, B, "result")
                 assert torch.equal(s2, sf), (n, B, "optimiser state")          # (canonical copy of the state blob — B x (160 B state + 64 B pose record) — byte for byte)
-    finally:
-        if old is None:
-            os.environ.pop("PCL_GD_FUSE_BLOCKS", None)
-        else:
-            os.environ["PCL_GD_FUSE_BLOCKS"] = old
 
 
 def test_small_problems_replay_a_cached_graph_and_stay_bit_identical(oracle):
@@ -841,21 +840,21 @@ def test_hist_trim_tile_binned_equals_the_zbuffer_path(oracle):
             cloud = ops.Cloud(X, C)
             out = {}
             for mode in ("1", "0"):
-                os.environ["PCL_HIST_SPLAT"] = mode
-                out[mode] = ops.hist_trim_scores(I, cloud, T_, R_, nh, nw, batch=4, return_parts=True)
+                out[mode] = ops.hist_trim_scores(I, cloud, T_, R_, nh, nw, batch=4, return_parts=True, splat=mode == "1")
             for a, b in zip(out["1"], out["0"]):
                 assert torch.equal(a, b), (img.shape, len(xyz))
             assert float(out["0"][0].abs().sum()) > 0
     finally:
-        os.environ.pop("PCL_HIST_SPLAT", None)
+        pass
 
 
 @pytest.mark.gpu
 def test_results_do_not_depend_on_the_block_to_xcd_mapping():
     """Which XCD evaluates which chunk, and in which order (contiguous ranges, interleaved chunks, odd iterations walking
     backwards), is scheduling only: every chunk's partial sums land in its own slot and the second-stage sum runs over the
-    slots in index order, so a multi-round refinement must come out bit for bit the same under every mapping.  The knobs are
-    read once per process: one child process per setting."""
+    slots in index order, so a multi-round refinement must come out bit for bit the same under every mapping.  The knobs exist
+    in the EXPERIMENTS build only (lib/libpiccolo_hip_exp.so, -DPCL_EXPERIMENTS; the shipped library reads no environment variable)
+    and are read once per process: one child process per setting, plus one with the shipped library — same digest."""
     import hashlib
     import os
     import subprocess
@@ -875,9 +874,11 @@ def test_results_do_not_depend_on_the_block_to_xcd_mapping():
         "gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr).cuda(), torch.from_numpy(ro).cuda(), ops.quantile_box(X, 0.05), lr=0.1, factor=0.9, patience=5)\n"
         "gd.run(25)\n"
         "print(hashlib.sha256(gd.result().cpu().numpy().tobytes()).hexdigest())\n")
+    from piccolo_amd import build as hip_build
+    exp_so = hip_build.build_experiments()                  # (prebuilt by __graft_entry__.build(); compiled here if missing or stale)
     digests = {}
-    for runs, flip in (("0", "1"), ("1", "0"), ("4", "1"), ("0", "0")):
-        env = dict(os.environ, PCL_XCD_RUNS=runs, PCL_FLIP=flip)
+    for runs, flip in (("0", "1"), ("1", "0"), ("4", "1"), ("0", "0"), (None, None)):
+        env = dict(os.environ, PCL_XCD_RUNS=runs, PCL_FLIP=flip, PCL_SO=exp_so) if runs is not None else {k: v for k, v in os.environ.items() if k != "PCL_SO"}
         out = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[(runs, flip)] = out.stdout.strip().splitlines()[-1]

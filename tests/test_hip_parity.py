@@ -565,15 +565,15 @@ def test_standalone_ops_are_differentiable_like_the_reference(ops, oracle, parit
     for fmt in ("auto", "f32"):
         from piccolo_amd import omniloc as po
         po._cache.clear()
-        import os
-        os.environ["PCL_PANO_FMT"] = "f32" if fmt == "f32" else "f16"
+        from piccolo_amd import ops as _ops
+        _ops.EXPERIMENT.pano_fmt = "f32" if fmt == "f32" else "f16"
         try:
             img, c = T(g["img"]).requires_grad_(), T(g["coord"]).requires_grad_()
             col = utils.sample_from_img(img, c)
             assert col.requires_grad
             col.backward(T(g["grad_rgb_in"]))
         finally:
-            os.environ.pop("PCL_PANO_FMT", None)
+            _ops.EXPERIMENT.pano_fmt = None
         gap_c = np.abs(g["grad_coord_f32"] - g["grad_coord_f64"]).max()
         gap_i = np.abs(g["grad_img_f32"] - g["grad_img_f64"]).max()
         # (coordinates stored as float32(0.99) sit inside the fp32 clip range and outside the fp64 one: they are compared
@@ -1072,12 +1072,10 @@ def test_shipped_shape_end_to_end_as_close_to_the_reference_as_it_is_to_itself(o
         r = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), cfg, {})
         t, R = r[0].numpy().reshape(3), r[1].numpy()
         rows.append(np.concatenate([t, R.reshape(-1), [float(r[2])], synth.pose_errors(t, R, t_gt, R_gt)]))
-        os.environ["PCL_GD_FUSE_BLOCKS"] = "0"
         try:
             po._cache.clear()
-            r2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(gd_graph=False, **cfg.__dict__), {})
+            r2 = po.omniloc_batch(I, X, C, T(trans.copy()), T(rot.copy()), Cfg(gd_graph=False, gd_fuse=False, **cfg.__dict__), {})
         finally:
-            del os.environ["PCL_GD_FUSE_BLOCKS"]
             po._cache.clear()
         assert all(torch.equal(a, b) for a, b in zip(r, r2)), s
     g22_compare(np.array(rows), g["batch"], parity)

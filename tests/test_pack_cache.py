@@ -78,7 +78,7 @@ def test_debug_visualize_host_helper(monkeypatch):
 
 def test_levels_tag_follows_the_tensor_version():
     """synth.mark_levels tags an image as 'every value exactly k/255 by construction' so that packing it never reads the
-    device-side exactness flag back; an in-place change afterwards voids the tag, PCL_VERIFY_LEVELS=1 ignores it (host logic)."""
+    device-side exactness flag back; an in-place change afterwards voids the tag, ops.EXPERIMENT.verify_levels ignores it (host logic)."""
     import os
     import torch
     from piccolo_amd import ops, synth
@@ -89,8 +89,8 @@ def test_levels_tag_follows_the_tensor_version():
     assert not ops._known_levels(img)                                                       # changed in place after tagging
     img2 = synth.quantise_like_image_file(torch.rand(4, 8, 3) * 255)
     assert ops._known_levels(img2) and bool((img2 * 255 == torch.round(img2 * 255)).all())
-    os.environ["PCL_VERIFY_LEVELS"] = "1"
+    ops.EXPERIMENT.verify_levels = True
     try:
         assert not ops._known_levels(img2)
     finally:
-        del os.environ["PCL_VERIFY_LEVELS"]
+        ops.EXPERIMENT.verify_levels = False

@@ -19,6 +19,7 @@ if sys.argv[1] == "cmp":
     sys.exit(0 if ok else 1)
 
 from bench import WORKLOADS  # noqa: E402
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth  # noqa: E402
 
 tag, wl = sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "cfg2")

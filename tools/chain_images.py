@@ -1,6 +1,7 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth
 N, H, W, B = 166_667, 1024, 2048, 6
 dev = torch.device("cuda:0")

@@ -22,6 +22,7 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from oracle import oracle                      # noqa: E402  (a measurement tool, not the product)
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import synth                  # noqa: E402
 
 

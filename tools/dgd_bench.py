@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, '.')
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

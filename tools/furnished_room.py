@@ -5,6 +5,7 @@ default grid (pcl_depth_default), mask on the panorama's own grid (round 4's def
 import sys
 import numpy as np, torch
 sys.path.insert(0, '.')
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth
 N, H, W, B = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000, 1024, 2048, 32
 xyz, rgb = synth.furnished_room(N, 0); X, C = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda()

@@ -3,6 +3,7 @@ import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops
 from test_oracle_golden import G23_CONFIGS, g23_case
 g = np.load(os.path.join(REPO, "tests/golden/g23_make_input.npz"))

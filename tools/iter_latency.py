@@ -5,6 +5,7 @@ spread=1: starting poses all over the room (what make_input hands over), 0: near
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 166_667
 if N < 0:                  # sweep of the spread modes in one process: python tools/iter_latency.py -166667 6

@@ -5,6 +5,7 @@ gaps and ramps overlap?   python tools/multi_stream_chains.py [n_points]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 166_667
 H, W, B, I = 1024, 2048, 6, 8

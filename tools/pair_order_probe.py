@@ -5,6 +5,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth, utils
 from piccolo_amd import omniloc as po
 N, H, W, B, I = 166_667, 1024, 2048, 6, 8

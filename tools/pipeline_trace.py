@@ -51,6 +51,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bench  # noqa: E402
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import omniloc as po, utils, synth  # noqa: E402
 
 n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 6

@@ -6,6 +6,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth, utils
 H, W = [int(v) for v in os.environ.get("PCL_TOOL_HW", "1024x2048").split("x")]
 dev = torch.device("cuda:0")

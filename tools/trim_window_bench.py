@@ -12,6 +12,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth, utils  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 166_667

@@ -3,6 +3,7 @@ rocprofv3 --pmc ... -- python3 tools/zcount.py depth_h depth_w stride [B]"""
 import sys
 import torch
 sys.path.insert(0, '.')
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import ops, synth  # noqa: E402
 dh, dw, stride = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 32

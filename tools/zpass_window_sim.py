@@ -4,6 +4,7 @@ Morton run fall outside an LDS window / a coarse-tile cache, and how many 64-byt
 import sys, numpy as np
 sys.path.insert(0,'.')
 from oracle import oracle
+import _knobs  # noqa: F401  (PCL_* experiment variables -> experiments build / ops.EXPERIMENT; tools/_knobs.py)
 from piccolo_amd import synth
 N=1_000_000
 xyz,rgb=synth.box_room(N,0)
