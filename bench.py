@@ -330,8 +330,15 @@ class Ranks:
                 except Exception:                                   # noqa: BLE001
                     pass
                 try:
-                    dist.init_process_group("gloo", init_method="tcp://%s:%d" % (os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1),
-                                            rank=self.rank, world_size=self.world, timeout=tmo)
+                    # a store of its own for the new group: under torch.distributed.run the AGENT hosts the store on MASTER_PORT and every
+                    # rank is a client of it (nobody would host another port); without an agent rank 0 hosts one on MASTER_PORT + 1
+                    addr, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])
+                    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+                        store = dist.TCPStore(addr, port, self.world, False, tmo)
+                    else:
+                        store = dist.TCPStore(addr, port + 1, self.world, self.rank == 0, tmo)
+                    dist.init_process_group("gloo", store=dist.PrefixStore("pcl_gloo_fallback", store), rank=self.rank, world_size=self.world,
+                                            timeout=tmo)
                 except Exception as exc2:                           # noqa: BLE001
                     self.fail("init_process_group(gloo fallback)", exc2)
                 self.backend = "gloo"

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCL_ABI_VERSION 9 /* 9: pcl_gd_hyper.fuse, pcl_loss_depth_workspace_bytes takes the occluder stride, the library reads no environment variable; 8: PCL_PANO_U8V / pcl_pano_pack_u8v; 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
+#define PCL_ABI_VERSION 9 /* 9: pcl_gd_hyper.fuse, pcl_loss_depth_workspace_bytes takes the occluder stride, pcl_trim_order + the `order` argument of pcl_trim_loss[_images], the library reads no environment variable; 8: PCL_PANO_U8V / pcl_pano_pack_u8v; 7: depth mask on its own grid (pcl_gd_hyper.depth_h / depth_w, pcl_depth_default, pcl_sampling_loss_depth), refresh rule and pcl_gd_depth_refresh_counts removed, pcl_gd_step_from_grads; 6: pcl_select_poses, pcl_gd_set_pano_groups, pcl_gd_winner; 2: fp16-level texels, colour preprocessing, histograms, dataset text reader; 3: backward of the stand-alone ops; 4: pcl_hist_trim_workspace_bytes_n; 5: pcl_source_hash, pcl_timer_calibrate, pcl_trim_*, pcl_gd_plan */
 
 #define PCL_EINVAL (-1)   /* bad size / null pointer / unsupported argument */
 #define PCL_EWORKSPACE (-2) /* workspace too small */
@@ -319,16 +319,29 @@ int pcl_select_poses(const float *values, int nprob, int M, int n_keep, int larg
 int pcl_trim_groups(const float *rot, int R, void *groups, void *stream);
 size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups);
 int pcl_trim_loss(const float *cloud, int64_t n, const void *pano, int pano_format, int H, int W, const float *trans, int K,
-                  const float *rot, int R, const void *groups, int ngroups, float *loss_table, float *count_table,
+                  const float *rot, int R, const void *groups, int ngroups, const void *order, float *loss_table, float *count_table,
                   void *workspace, size_t workspace_bytes, void *stream);
+/* The launch's WORK LIST (ABI 9; `order`, nullable, of pcl_trim_loss / pcl_trim_loss_images).  Which block evaluates which (cloud chunk,
+ * (translation, rotation class) slot) item is scheduling only — every item's partial sum has its own place, the tables are bit-identical
+ * with any list or none — but it decides what the caches see: in plain (chunk, slot) order every pose streams its own region of the
+ * panorama through the L2s (1M points x 1800 poses: 16.4 GB through the memory side for 41 MB of unique data).  pcl_trim_order ranks the
+ * items by the panorama ROW their chunk's centroid projects to (the row does not depend on the yaw), cuts the ranking into bands of about
+ * 2.5 MB of texture rows and deals the XCDs contiguous eighths: an XCD's L2 then holds one band of the texture for all the poses
+ * (6.6 GB, L2 hit 0.70 -> 0.88).  The list depends on the cloud, the candidate grid and the panorama's size / texel layout, NOT on the query
+ * image: build it once per room (two radix sorts of chunks x slots keys) and pass it to every image's launch.  A list built for another
+ * cloud size or grid is ignored by the kernel (plain order).  order: pcl_trim_order_bytes(n, K, ngroups) bytes. */
+size_t pcl_trim_order_bytes(int64_t n, int K, int ngroups);
+size_t pcl_trim_order_workspace_bytes(int64_t n, int K, int ngroups);
+int pcl_trim_order(const float *cloud, int64_t n, int pano_format, int H, int W, const float *trans, int K, const float *rot, int R,
+                   const void *groups, int ngroups, void *order, void *workspace, size_t workspace_bytes, void *stream);
 /* The same for `nimages` query images of ONE room in one launch (the image loop of localize.py:143-223: the candidate grid
  * depends on the cloud only, utils.py:613-616): panos_host = HOST array of nimages device addresses of packed panoramas (one
  * size and texel format; nimages <= 32), loss_tables / count_tables [nimages][K][R].  The cloud is cut into the chunks of the
  * single-image launch, so every image's table has the bits pcl_trim_loss gives it. */
 size_t pcl_trim_loss_images_workspace_bytes(int64_t n, int K, int ngroups, int nimages);
 int pcl_trim_loss_images(const float *cloud, int64_t n, const void *const *panos_host, int nimages, int pano_format, int H, int W,
-                         const float *trans, int K, const float *rot, int R, const void *groups, int ngroups, float *loss_tables,
-                         float *count_tables, void *workspace, size_t workspace_bytes, void *stream);
+                         const float *trans, int K, const float *rot, int R, const void *groups, int ngroups, const void *order,
+                         float *loss_tables, float *count_tables, void *workspace, size_t workspace_bytes, void *stream);
 /* Scatter-min depth mask on the PACKED cloud for B poses (build-defined: the reference imports torch_scatter.scatter_min at
  * utils.py:6 and never calls it; off by default in the loss).  Seen from pose b, every point falls into one cell of an H x W grid by
  * make_pano's pixel formula (utils.py:158-165) — the DEPTH grid, chosen by point density, not the panorama's resolution: a z-buffer

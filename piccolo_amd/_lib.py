@@ -70,9 +70,12 @@ SIGNATURES = {
     "pcl_trim_groups_bytes": (_sz, [_int]),
     "pcl_trim_groups": (_int, [_vp, _int, _vp, _vp]),
     "pcl_trim_loss_workspace_bytes": (_sz, [_i64, _int, _int]),
-    "pcl_trim_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_trim_loss": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_trim_order_bytes": (_sz, [_i64, _int, _int]),
+    "pcl_trim_order_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "pcl_trim_order": (_int, [_vp, _i64, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _sz, _vp]),
     "pcl_trim_loss_images_workspace_bytes": (_sz, [_i64, _int, _int, _int]),
-    "pcl_trim_loss_images": (_int, [_vp, _i64, _c.POINTER(_vp), _int, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pcl_trim_loss_images": (_int, [_vp, _i64, _c.POINTER(_vp), _int, _int, _int, _int, _vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcl_depth_workspace_bytes": (_sz, [_int, _int, _int]),
     "pcl_depth_mask": (_int, [_vp, _i64, _vp, _vp, _int, _int, _int, _c.c_float, _int, _vp, _vp, _sz, _vp]),
     "pcl_gd_init": (_int, [_vp, _vp, _vp, _int, _c.POINTER(GdHyper), _vp]),

@@ -23,6 +23,8 @@
 // are; pairs come back as the reference's row-major loss_table[i, j] (utils.py:497).
 #include <stdlib.h>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "pcl_sample_device.h"
 
 #define PCL_TRIM_Y 4        // yaws evaluated per loaded point pair (partials row = PCL_TRIM_Y x {sum ||d||, count} = PCL_NACC floats)
@@ -200,6 +202,7 @@ struct PclTrimArgs {
     int K, nslots;                   // nslots = ngroups (host's count) * K, per image
     float* partials;                 // [nchunks][nimages * nslots][PCL_TRIM_Y][2]
     int nchunks, seg_len, steps_base, steps_rem;
+    const int* order;                // nullable: pcl_trim_order's blob — header, then [nchunks * nslots] items = chunk * nslots + slot
 };
 
 #define PCL_STEP (2 * PCL_BLOCK)
@@ -277,7 +280,17 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_kernel(PclTrimArgs a)
     //  single-image launch, so every (image, slot, chunk) partial sum — and with it the table — has the single-image launch's bits)
     const int nslots_all = a.nimages * a.nslots;
     int image, slot, slot_all, chunk;
-    if (a.xcd_images) {
+    if (a.order && a.order[0] == 0x524f5450 && a.order[1] == a.nchunks && a.order[2] == a.nslots) {   // (a list of another cloud / grid: plain mapping)
+        // ROW-SORTED work list (round 6, pcl_trim_order): XCD x evaluates its contiguous eighth of the list — the (chunk, slot) items whose
+        // chunk lands in its bands of panorama rows, band after band, chunk-major inside a band — image after image, so that its L2 holds a
+        // band of ONE texture for all the poses instead of every pose streaming its own region through it
+        const int per_band = (a.nchunks * a.nslots) >> 3, idx = (int)(blockIdx.x >> 3);
+        image = idx / per_band;
+        const int item = a.order[64 + (int)(blockIdx.x & 7) * per_band + (idx - image * per_band)];
+        chunk = item / a.nslots;
+        slot = item - chunk * a.nslots;
+        slot_all = image * a.nslots + slot;
+    } else if (a.xcd_images) {
         // XCD <-> images (round 4; nimages a multiple of 8, small cloud): XCD x takes the images x, x + 8, ... over all chunks, so its
         // L2 holds one image's texture and the whole cloud instead of an eighth of the cloud and every texture of the launch
         const int ipx = a.nimages >> 3, j = (int)(blockIdx.x >> 3), r = j / ipx;
@@ -461,12 +474,179 @@ __global__ void __launch_bounds__(256) pcl_trim_finish_kernel(const float* __res
 
 static size_t trim_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// ---------------------------------------------------------------- the row-sorted work list (round 6)
+// Why.  Every (chunk, slot) block streams its own region of the texture: with the blocks in (chunk, slot) order an XCD's L2 sees, for one
+// chunk, the regions of hundreds of views all over the panorama — no line is touched twice before it is evicted, and the launch moved
+// 16-18 GB through the memory side for 41 MB of unique data (1M points, 1800 poses, `U8V` texels).  The ROW a chunk
+// lands in does not depend on the yaw (the four yaws of a slot share theta) and is known from the chunk's centroid: rank the items by
+// that row, cut the ranking into `bands` equal parts (a multiple of 8), give every XCD a contiguous eighth of them and walk each band
+// chunk by chunk.  An XCD's L2 then holds one band of the texture (2 MB of 17) for ALL the poses: 16.4 -> 6.6 GB per launch, L2 hit
+// 0.70 -> 0.88 (tools/trim_order_proto.py, profiles/r06).  The list depends on the cloud, the candidate grid and the texture's size —
+// not on the query image: it is built ONCE per room (pcl_trim_order; two radix sorts of chunks x slots keys) and handed to every
+// image's launch.  The partial sum of every (chunk, slot) is what it was: tables are bit-identical with and without the list.
+struct PclTrimOrderHdr {
+    int magic, nchunks, nslots, bands;
+    int pad[60];
+};
+static_assert(sizeof(PclTrimOrderHdr) == 256, "trim order header");
+#define PCL_TRIM_ORDER_MAGIC 0x524f5450
+
+struct PclTrimSortArgs {
+    const float* cloud;
+    int64_t n, stride;
+    const PclPoseRec* poses;
+    int nslots, nchunks, steps_base, steps_rem, bands;
+    float* cent;                    // [nchunks][4]: centroid of the chunk's points, count
+};
+
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_centroid_kernel(PclTrimSortArgs a)
+{
+    const int chunk = blockIdx.x;
+    const int first = chunk * a.steps_base + min(chunk, a.steps_rem), nsteps = a.steps_base + (chunk < a.steps_rem ? 1 : 0);
+    const int64_t begin = (int64_t)first * (2 * PCL_BLOCK);
+    int64_t end = begin + (int64_t)nsteps * (2 * PCL_BLOCK);
+    if (end > a.n) end = a.n;
+    float sx = 0.f, sy = 0.f, sz = 0.f, cnt = 0.f;
+    for (int64_t i = begin + threadIdx.x; i < end; i += PCL_BLOCK) {
+        sx += a.cloud[i]; sy += a.cloud[a.stride + i]; sz += a.cloud[2 * a.stride + i]; cnt += 1.f;
+    }
+    __shared__ float red[PCL_BLOCK / PCL_WAVE][4];
+    sx = pcl_wave_sum(sx); sy = pcl_wave_sum(sy); sz = pcl_wave_sum(sz); cnt = pcl_wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { float* r = red[threadIdx.x >> 6]; r[0] = sx; r[1] = sy; r[2] = sz; r[3] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const float c = red[0][3] + red[1][3] + red[2][3] + red[3][3];
+        a.cent[4 * chunk + threadIdx.x] = threadIdx.x < 3 ? (c > 0.f ? v / c : 0.f) : c;
+    }
+}
+
+// key of item = chunk * nslots + slot: the panorama row (16 bits) of the chunk's centroid seen from the slot's pose
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_rowkey_kernel(PclTrimSortArgs a, unsigned int* __restrict__ key, unsigned int* __restrict__ val)
+{
+    const int item = blockIdx.x * PCL_BLOCK + threadIdx.x;
+    if (item >= a.nchunks * a.nslots) return;
+    const int chunk = item / a.nslots, slot = item - chunk * a.nslots;
+    const PclPoseRec* p = a.poses + slot;
+    const float cx = a.cent[4 * chunk] - p->t[0], cy = a.cent[4 * chunk + 1] - p->t[1], cz = a.cent[4 * chunk + 2] - p->t[2];
+    const float qx = p->R[0] * cx + p->R[1] * cy + p->R[2] * cz, qy = p->R[3] * cx + p->R[4] * cy + p->R[5] * cz;
+    const float qz = p->R[6] * cx + p->R[7] * cy + p->R[8] * cz;
+    const float el = atan2f(qz, sqrtf(qx * qx + qy * qy));                       // elevation: the row, monotonically
+    const float f = (0.5f - el * 0.31830988618379067154f) * 65535.f;
+    key[item] = f == f ? (unsigned int)fminf(fmaxf(f, 0.f), 65535.f) : 0u;        // (a slot beyond the table's groups has no pose: anywhere)
+    val[item] = (unsigned int)item;
+}
+
+// position in the row ranking -> band; second key = band * nchunks + chunk (chunk-major inside the band)
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_bandkey_kernel(PclTrimSortArgs a, const unsigned int* __restrict__ ranked, unsigned int* __restrict__ key)
+{
+    const int pos = blockIdx.x * PCL_BLOCK + threadIdx.x;
+    const int M = a.nchunks * a.nslots;
+    if (pos >= M) return;
+    const int band = (int)(((int64_t)pos * a.bands) / M);
+    key[pos] = (unsigned int)(band * a.nchunks + (int)(ranked[pos] / (unsigned int)a.nslots));
+}
+
+__global__ void pcl_trim_order_hdr_kernel(PclTrimOrderHdr* h, int nchunks, int nslots, int bands)
+{
+    if (threadIdx.x == 0) { h->magic = PCL_TRIM_ORDER_MAGIC; h->nchunks = nchunks; h->nslots = nslots; h->bands = bands; }
+}
+
+static size_t trim_sort_temp_bytes(size_t M)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned int*, unsigned int*, const unsigned int*, unsigned int*>(
+        nullptr, bytes, nullptr, nullptr, nullptr, nullptr, M, 0, 32, nullptr, false);
+    return bytes;
+}
+
+// bands: a multiple of 8, sized so that one band of the texture is about 2 MB (an XCD's L2 is 4 MB and also holds the cloud chunks)
+static int trim_bands(int pano_format, int H, int W)
+{
+    const int64_t tex = (int64_t)(H + 3) * (W + 2) * (pano_format == PCL_PANO_U8P ? 4 : pano_format == PCL_PANO_U8V ? 8 : pcl_texel_bytes(pano_format));
+    int per_xcd = (int)((tex / 8 + PCL_KNOB(TRIM_BAND_BYTES, 2500000) - 1) / PCL_KNOB(TRIM_BAND_BYTES, 2500000));
+    if (per_xcd < 1) per_xcd = 1;
+    if (per_xcd > 64) per_xcd = 64;
+    return 8 * per_xcd;
+}
+
 static size_t trim_workspace_bytes(int64_t n, int K, int ngroups, int nimages)
 {
     if (n <= 0 || K <= 0 || ngroups <= 0 || nimages <= 0) return 0;
     int nchunks, seg_len, sb, sr;
     pcl_plan_for_groups(n, ngroups * K, &nchunks, &seg_len, &sb, &sr);
     return trim_align((size_t)ngroups * K * sizeof(PclPoseRec)) + trim_align((size_t)nchunks * nimages * ngroups * K * PCL_NACC * sizeof(float));
+}
+
+static int trim_plan_chunks(int64_t n, int nslots)
+{
+    int nchunks, seg_len, sb, sr;
+    pcl_plan_for_groups(n, nslots, &nchunks, &seg_len, &sb, &sr);
+    return nchunks;
+}
+
+extern "C" size_t pcl_trim_order_bytes(int64_t n, int K, int ngroups)
+{
+    if (n <= 0 || K <= 0 || ngroups <= 0) return 0;
+    return sizeof(PclTrimOrderHdr) + trim_align((size_t)trim_plan_chunks(n, ngroups * K) * ngroups * K * sizeof(int));
+}
+
+extern "C" size_t pcl_trim_order_workspace_bytes(int64_t n, int K, int ngroups)
+{
+    if (n <= 0 || K <= 0 || ngroups <= 0) return 0;
+    const size_t nchunks = (size_t)trim_plan_chunks(n, ngroups * K), M = nchunks * ngroups * K;
+    return trim_align((size_t)ngroups * K * sizeof(PclPoseRec)) + trim_align(nchunks * 4 * sizeof(float)) + 3 * trim_align(M * sizeof(int)) +
+           trim_align(trim_sort_temp_bytes(M));
+}
+
+extern "C" int pcl_trim_order(const float* cloud, int64_t n, int pano_format, int H, int W, const float* trans, int K, const float* rot, int R,
+                              const void* groups, int ngroups, void* order, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!cloud || !trans || !rot || !groups || !order || !workspace) return PCL_EINVAL;
+    if (n <= 0 || n > PCL_MAX_POINTS || K <= 0 || R <= 0 || ngroups <= 0 || ngroups > R || H <= 0 || W <= 0) return PCL_EINVAL;
+    if (pano_format < PCL_PANO_F32 || pano_format > PCL_PANO_U8V) return PCL_EINVAL;
+    const int nslots = ngroups * K;
+    if ((int64_t)nslots > (1 << 24)) return PCL_EINVAL;
+    if (workspace_bytes < pcl_trim_order_workspace_bytes(n, K, ngroups)) return PCL_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const PclTrimHeader* hdr = (const PclTrimHeader*)groups;
+    const PclTrimGroup* grs = (const PclTrimGroup*)(hdr + 1);
+    PclTrimSortArgs so;
+    int seg_len;
+    pcl_plan_for_groups(n, nslots, &so.nchunks, &seg_len, &so.steps_base, &so.steps_rem);
+    const int64_t M64 = (int64_t)so.nchunks * nslots;
+    if (M64 > 0x3fffffffll) return PCL_EINVAL;
+    const size_t M = (size_t)M64;
+    so.cloud = cloud; so.n = n; so.stride = pcl_cloud_stride(n); so.nslots = nslots;
+    so.bands = trim_bands(pano_format, H, W);
+    char* w = (char*)workspace;
+    PclPoseRec* recs = (PclPoseRec*)w; w += trim_align((size_t)nslots * sizeof(PclPoseRec));
+    so.poses = recs;
+    so.cent = (float*)w; w += trim_align((size_t)so.nchunks * 4 * sizeof(float));
+    unsigned int* k0 = (unsigned int*)w; w += trim_align(M * sizeof(int));
+    unsigned int* k1 = (unsigned int*)w; w += trim_align(M * sizeof(int));
+    unsigned int* v0 = (unsigned int*)w; w += trim_align(M * sizeof(int));
+    void* temp = w;
+    size_t temp_bytes = trim_sort_temp_bytes(M);
+    PclTrimOrderHdr* oh = (PclTrimOrderHdr*)order;
+    unsigned int* list = (unsigned int*)(oh + 1);
+    hipLaunchKernelGGL(pcl_trim_pose_setup_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, trans, rot, K, hdr, grs, ngroups, recs);
+    hipLaunchKernelGGL(pcl_trim_centroid_kernel, dim3(so.nchunks), dim3(PCL_BLOCK), 0, s, so);
+    const unsigned nb = (unsigned)((M + PCL_BLOCK - 1) / PCL_BLOCK);
+    hipLaunchKernelGGL(pcl_trim_rowkey_kernel, dim3(nb), dim3(PCL_BLOCK), 0, s, so, k0, v0);
+    PCL_LAUNCH_CHECK();
+    // rank by row (16-bit keys, stable): v0 -> list
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned int*)k0, k1, (const unsigned int*)v0, list, M, 0, 16, s, false);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pcl_trim_bandkey_kernel, dim3(nb), dim3(PCL_BLOCK), 0, s, so, (const unsigned int*)list, k0);
+    e = hipMemcpyAsync(v0, list, M * sizeof(int), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    // (band, chunk)-major, stable: inside a cell the row ranking survives
+    e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned int*)k0, k1, (const unsigned int*)v0, list, M, 0, 32, s, false);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(pcl_trim_order_hdr_kernel, dim3(1), dim3(64), 0, s, oh, so.nchunks, nslots, so.bands);
+    PCL_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" size_t pcl_trim_loss_workspace_bytes(int64_t n, int K, int ngroups) { return trim_workspace_bytes(n, K, ngroups, 1); }
@@ -476,8 +656,8 @@ extern "C" size_t pcl_trim_loss_images_workspace_bytes(int64_t n, int K, int ngr
 }
 
 extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* const* panos_host, int nimages, int pano_format, int H, int W,
-                                    const float* trans, int K, const float* rot, int R, const void* groups, int ngroups, float* loss_tables,
-                                    float* count_tables, void* workspace, size_t workspace_bytes, void* stream)
+                                    const float* trans, int K, const float* rot, int R, const void* groups, int ngroups, const void* order,
+                                    float* loss_tables, float* count_tables, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (!cloud || !panos_host || !trans || !rot || !groups || !loss_tables || !workspace) return PCL_EINVAL;
     if (nimages <= 0 || nimages > PCL_TRIM_MAX_IMAGES) return PCL_EINVAL;
@@ -518,6 +698,7 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
     pcl_plan_for_groups(n, nslots, &a.nchunks, &a.seg_len, &a.steps_base, &a.steps_rem);
     const int64_t nblk = (int64_t)a.nchunks * nslots * nimages;
     if (nblk > 0x7fffffffll) return PCL_EINVAL;
+    a.order = (const int*)order;
     if (pano_format == PCL_PANO_U8P) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8P>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_U8V) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8V>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
     else if (pano_format == PCL_PANO_U8) hipLaunchKernelGGL(pcl_trim_kernel<PCL_PANO_U8>, dim3((unsigned)nblk), dim3(PCL_BLOCK), 0, s, a);
@@ -530,9 +711,9 @@ extern "C" int pcl_trim_loss_images(const float* cloud, int64_t n, const void* c
 }
 
 extern "C" int pcl_trim_loss(const float* cloud, int64_t n, const void* pano, int pano_format, int H, int W, const float* trans, int K,
-                             const float* rot, int R, const void* groups, int ngroups, float* loss_table, float* count_table,
+                             const float* rot, int R, const void* groups, int ngroups, const void* order, float* loss_table, float* count_table,
                              void* workspace, size_t workspace_bytes, void* stream)
 {
-    return pcl_trim_loss_images(cloud, n, &pano, 1, pano_format, H, W, trans, K, rot, R, groups, ngroups, loss_table, count_table, workspace,
-                                workspace_bytes, stream);
+    return pcl_trim_loss_images(cloud, n, &pano, 1, pano_format, H, W, trans, K, rot, R, groups, ngroups, order, loss_table, count_table,
+                                workspace, workspace_bytes, stream);
 }

@@ -181,6 +181,19 @@ def trim_texels(n, H, W):
     return "u8p" if 20 * n < 9 * px else "u8v" if 5 * n >= 3 * px else "u8"
 
 
+def trim_order_pays(n, H, W, fmt):
+    """Does the trim launch of an n-point cloud against an H x W panorama in texel layout `fmt` (code) take the row-sorted work list
+    (TrimOrder)?  Measured per 1800-pose launch, plain (chunk, slot) order -> with the list (tools/trim_u8p.py, round 6; tables bit-identical):
+        2048 x 1024: 167k u8p 0.83 -> 0.74 ms, 400k u8p 1.51 -> 1.44, 1M u8v 3.17 -> 3.07 (memory-side 16.4 -> 6.6 GB, L2 hit 0.70 -> 0.88),
+                     2M u8v 5.78 -> 5.52; 8 images per launch: 167k 0.747 -> 0.685 per image, 1M 3.10 -> 3.05
+        1024 x  512: 100k u8v 0.38 -> 0.38, 500k 1.36 -> 1.35                                      (the texture lives in one L2 either way)
+        4096 x 2048: 3M u8p 10.19 -> 10.48 (u8 11.2 -> 11.8, u8v 13.6 -> 13.1), 10M u8v 28.2 -> 28.1
+    i.e. always up to cfg 2's texture class; for larger panoramas only with vertical-pair texels (a band of a 67 MB texture is several
+    L2s wide whatever the order, and a sparse cloud's launch is bound by texture lines, not by where they come from)."""
+    doubled = 8 * (int(H) + 2) * (int(W) + 2)
+    return doubled <= 24_000_000 or int(fmt) == _lib.PANO_U8V
+
+
 def _known_levels(img):
     """True for a tensor tagged by synth.mark_levels (every value exactly k/255 by construction); EXPERIMENT.verify_levels ignores
     the tag (the device-side check is then read back as for any other tensor)."""
@@ -273,9 +286,28 @@ class TrimGroups:
         self.ngroups = int(self.data[:4].view(torch.int32).item())
 
 
-def trim_loss_table(cloud, pano, trans, groups, return_count=False):
+class TrimOrder:
+    """The trim launch's row-sorted work list (pcl_trim_order): which (cloud chunk, slot) item each block evaluates, ranked by the
+    panorama row the chunk lands in so that an XCD's L2 holds a band of the texture for all the poses.  Depends on the cloud, the
+    candidate grid and the panorama's size / texel layout — not on the query image: build once per room, pass to trim_loss_table[s]
+    (scheduling only: tables are bit-identical with or without it)."""
+
+    def __init__(self, cloud, pano_shape, trans, groups):
+        """pano_shape = (H, W, texel format code) of the panoramas the launches will read"""
+        lib = _lib.load()
+        trans = _dev(trans).reshape(-1, 3)
+        H, W, fmt = pano_shape
+        self.key = (cloud.n, int(trans.shape[0]), groups.ngroups, int(H), int(W), int(fmt))
+        self.data = _bytes(lib.pcl_trim_order_bytes(cloud.n, self.key[1], groups.ngroups))
+        nws = lib.pcl_trim_order_workspace_bytes(cloud.n, self.key[1], groups.ngroups)
+        ws = _bytes(nws)
+        _lib.check(lib.pcl_trim_order(_ptr(cloud.data), cloud.n, int(fmt), int(H), int(W), _ptr(trans), self.key[1], _ptr(groups.rot), groups.R,
+                                      _ptr(groups.data), groups.ngroups, _ptr(self.data), _ptr(ws), nws, _stream()), "pcl_trim_order")
+
+
+def trim_loss_table(cloud, pano, trans, groups, return_count=False, order=None):
     """utils.py:484-499 for all pairs: (K, R) float GPU tensor loss_table[i, j] = forward-only sampling loss of (trans[i], rot[j]),
-    rotations of one (pitch, roll) class sharing the projection (csrc/pcl_trim.hip)."""
+    rotations of one (pitch, roll) class sharing the projection (csrc/pcl_trim.hip).  order: a TrimOrder of this cloud / grid."""
     lib = _lib.load()
     trans = _dev(trans).reshape(-1, 3)
     K = int(trans.shape[0])
@@ -284,7 +316,8 @@ def trim_loss_table(cloud, pano, trans, groups, return_count=False):
     nws = lib.pcl_trim_loss_workspace_bytes(cloud.n, K, groups.ngroups)
     ws = _bytes(nws)
     _lib.check(lib.pcl_trim_loss(_ptr(cloud.data), cloud.n, _ptr(pano.data), pano.fmt, pano.H, pano.W, _ptr(trans), K, _ptr(groups.rot),
-                                 groups.R, _ptr(groups.data), groups.ngroups, _ptr(table), _ptr(count), _ptr(ws), nws, _stream()),
+                                 groups.R, _ptr(groups.data), groups.ngroups, _ptr(order.data) if order is not None else None, _ptr(table), _ptr(count),
+                                 _ptr(ws), nws, _stream()),
                "pcl_trim_loss")
     return (table, count) if return_count else table
 
@@ -292,7 +325,7 @@ def trim_loss_table(cloud, pano, trans, groups, return_count=False):
 TRIM_MAX_IMAGES = 32       # pcl_trim_loss_images: query images per launch
 
 
-def trim_loss_tables(cloud, panos, trans, groups, return_count=False):
+def trim_loss_tables(cloud, panos, trans, groups, return_count=False, order=None):
     """trim_loss_table for several query images of one room in ONE launch: (I, K, R) float GPU tensor; image i's table has the
     bits of trim_loss_table(cloud, panos[i], ...) (same chunks of the cloud).  panos: list of Pano of one size / texel format."""
     lib = _lib.load()
@@ -309,8 +342,8 @@ def trim_loss_tables(cloud, panos, trans, groups, return_count=False):
         ws = _bytes(nws)
         arr = (ctypes.c_void_p * len(part))(*[p.data.data_ptr() for p in part])
         _lib.check(lib.pcl_trim_loss_images(_ptr(cloud.data), cloud.n, arr, len(part), p0.fmt, p0.H, p0.W, _ptr(trans), K, _ptr(groups.rot),
-                                            groups.R, _ptr(groups.data), groups.ngroups, _ptr(table[i0:]), _ptr(count[i0:]) if return_count else None,
-                                            _ptr(ws), nws, _stream()), "pcl_trim_loss_images")
+                                            groups.R, _ptr(groups.data), groups.ngroups, _ptr(order.data) if order is not None else None, _ptr(table[i0:]),
+                                            _ptr(count[i0:]) if return_count else None, _ptr(ws), nws, _stream()), "pcl_trim_loss_images")
     return (table, count) if return_count else table
 
 

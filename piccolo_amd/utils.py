@@ -166,6 +166,15 @@ def make_pano(xyz, rgb, resolution=(200, 400), return_torch=False):
 
 
 # ------------------------------------------------------------------------------------------------ initialisation
+def _trim_order(xyz, cloud, pano, trans, rot, groups):
+    """The trim launch's work list (ops.TrimOrder), cached per (cloud points, candidate grid, panorama size / texel layout): it does not
+    depend on the query image or on the colours.  None where a cache key cannot be formed (grids that are not tensors)."""
+    from .omniloc import _cached
+    if not (torch.is_tensor(trans) and torch.is_tensor(rot) and torch.is_tensor(xyz)) or not ops.trim_order_pays(cloud.n, pano.H, pano.W, pano.fmt):
+        return None
+    return _cached("trimorder", (xyz, trans, rot), lambda: ops.TrimOrder(cloud, (pano.H, pano.W, pano.fmt), trans, groups), sub=(pano.H, pano.W, pano.fmt))
+
+
 def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     """Keep the `num_input` (translation, rotation) pairs with the smallest sampling loss out of all K x R pairs.
     The reference loops K*R forwards in Python (utils.py:484-499); here all pairs go through ONE launch in which the rotations
@@ -179,7 +188,7 @@ def trim_input_loss(img, xyz, rgb, trans, rot, num_input):
     # the (pitch, roll) classes of the rotation table: once per table (the grid is cached per config in make_input)
     if Rn <= ops.TRIM_MAX_ROT:
         groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot)) if torch.is_tensor(rot) else ops.TrimGroups(rot)
-        table = ops.trim_loss_table(cloud, pano, trans, groups).reshape(-1)      # row-major (K, R) like the reference's loss_table
+        table = ops.trim_loss_table(cloud, pano, trans, groups, order=_trim_order(xyz, cloud, pano, trans, rot, groups)).reshape(-1)      # row-major (K, R) like the reference's loss_table
     else:
         # more rotations than the yaw-sharing launch classifies (its table of classes lives in LDS): the generic forward-only
         # kernel over all pairs, a slice of translations at a time
@@ -354,7 +363,7 @@ def make_input_images(imgs, xyz, rgb, num_input, init_dict=None, criterion="hist
     if len({p.fmt for p in panos}) > 1:                       # a launch needs one texel format: float4 holds any image
         panos = [ops.Pano(im, fmt="f32") for im in imgs]
     groups = _cached("trimgroups", (rot,), lambda: ops.TrimGroups(rot))
-    tables = ops.trim_loss_tables(cloud, panos, trans, groups).reshape(I, K * Rn)
+    tables = ops.trim_loss_tables(cloud, panos, trans, groups, order=_trim_order(xyz, cloud, panos[0], trans, rot, groups)).reshape(I, K * Rn)
     t1, r1 = ops.select_poses(tables, n_mid, trans, rot, largest=False, rot_per_trans=Rn)               # (I, n_mid, 3)
     scores = ops.hist_trim_scores_images(imgs, cloud, t1, r1, init_dict["num_split_h"], init_dict["num_split_w"])        # (I, n_mid)
     ft, fr = ops.select_poses(scores, min(num_input, n_mid), t1, r1, largest=True)                      # (I, num_input, 3)

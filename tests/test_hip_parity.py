@@ -284,6 +284,36 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
         assert torch.equal(t8, tp[0]) and torch.equal(t8, tp[1]), paired
         with pytest.raises(Exception):                     # nothing but the trim launch reads these layouts
             ops.sampling_loss(cloud, ops.Pano(img, fmt=paired), T(trans[:2]), T(stanford[:2]))
+    # The row-sorted WORK LIST (round 6, pcl_trim_order: which block evaluates which (chunk, slot) item, ranked by the panorama row the
+    # chunk lands in): scheduling only — every grid shape, every layout, one and several images per launch, panoramas of odd height:
+    # tables and counts bit-identical to the plain order; the list holds every item exactly once, in eight equal parts whose bands
+    # ascend; a list built for ANOTHER cloud size or grid is ignored by the kernel (plain order, same table).
+    for name, rot, tr, _ in cases[:4]:
+        groups = ops.TrimGroups(T(rot))
+        for fmt in ("u8", "u8p", "u8v"):
+            pano = ops.Pano(img, fmt=fmt)
+            order = ops.TrimOrder(cloud, (pano.H, pano.W, pano.fmt), T(tr), groups)
+            t0_, c0_ = ops.trim_loss_table(cloud, pano, T(tr), groups, return_count=True)
+            t1_, c1_ = ops.trim_loss_table(cloud, pano, T(tr), groups, return_count=True, order=order)
+            assert torch.equal(torch.nan_to_num(t0_, nan=-1.0), torch.nan_to_num(t1_, nan=-1.0)) and torch.equal(c0_, c1_), (name, fmt)
+        hdr = order.data[:16].view(torch.int32).cpu().numpy()
+        nchunks, nslots, bands = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        assert hdr[0] == 0x524f5450 and nslots == groups.ngroups * len(tr) and nchunks % 8 == 0 and bands % 8 == 0
+        items = order.data[256:256 + 4 * nchunks * nslots].view(torch.int32).cpu().numpy()
+        assert np.array_equal(np.sort(items), np.arange(nchunks * nslots)), name            # a permutation: every item once
+    groups = ops.TrimGroups(T(stanford))
+    pano = ops.Pano(img, fmt="u8v")
+    order = ops.TrimOrder(cloud, (pano.H, pano.W, pano.fmt), T(trans), groups)
+    want = ops.trim_loss_table(cloud, pano, T(trans), groups)
+    both = ops.trim_loss_tables(cloud, [pano, ops.Pano(img.flip(0).contiguous(), fmt="u8v")], T(trans), groups, order=order)
+    assert torch.equal(both[0], want) and torch.equal(both[1], ops.trim_loss_table(cloud, ops.Pano(img.flip(0).contiguous(), fmt="u8v"), T(trans), groups))
+    eight = ops.trim_loss_tables(cloud, [pano] * 8, T(trans), groups, order=order)           # (8 images: the XCD <-> image mapping gives way to the list)
+    assert all(torch.equal(eight[i], want) for i in range(8))
+    assert torch.equal(ops.trim_loss_table(cloud, pano, T(trans[:3]), groups, order=order), want[:3])      # a list of another grid: ignored
+    small = ops.Cloud(X[:20_000], C[:20_000])
+    assert torch.equal(ops.trim_loss_table(small, pano, T(trans), groups, order=order), ops.trim_loss_table(small, pano, T(trans), groups))
+    assert ops.trim_order_pays(1_000_000, 1024, 2048, pano.fmt) and ops.trim_order_pays(166_667, 1024, 2048, ops._lib.PANO_U8P)
+    assert ops.trim_order_pays(10_000_000, 2048, 4096, ops._lib.PANO_U8V) and not ops.trim_order_pays(3_000_000, 2048, 4096, ops._lib.PANO_U8P)
     assert [ops.trim_texels(n_, 1024, 2048) for n_ in (166_667, 700_000, 1_000_000)] == ["u8p", "u8", "u8v"]
     assert [ops.trim_texels(n_, 2048, 4096) for n_ in (3_000_000, 4_000_000, 10_000_000)] == ["u8p", "u8", "u8v"] and ops.trim_texels(100_000, 512, 1024) == "u8v"
     # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once

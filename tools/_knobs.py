@@ -9,7 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-C_KNOBS = ("PCL_G", "PCL_BLOCKS", "PCL_XCD_RUNS", "PCL_XCD_GROUPS", "PCL_TRIM_CHUNKS", "PCL_TRIM_RUNS", "PCL_TRIM_XCD_IMAGES", "PCL_GD_FUSE_BLOCKS",
+C_KNOBS = ("PCL_TRIM_BAND_BYTES", "PCL_G", "PCL_BLOCKS", "PCL_XCD_RUNS", "PCL_XCD_GROUPS", "PCL_TRIM_CHUNKS", "PCL_TRIM_RUNS", "PCL_TRIM_XCD_IMAGES", "PCL_GD_FUSE_BLOCKS",
            "PCL_ZPINGPONG", "PCL_FLIP", "PCL_ZFORM", "PCL_ZSECOND", "PCL_BIN_EXACT", "PCL_BIN_DEDUP", "PCL_RESOLVE_THREADS")
 
 if any(k in os.environ for k in C_KNOBS) and "PCL_SO" not in os.environ:

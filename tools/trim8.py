@@ -19,10 +19,11 @@ for k in range(I):
 rot = utils.generate_rot_points(bench.STANFORD_INIT, device=dev)
 trans = utils.generate_trans_points(X, bench.STANFORD_INIT, device=dev)
 groups, cloud = ops.TrimGroups(rot), ops.Cloud(X, C)
-t = ops.trim_loss_tables(cloud, panos, trans, groups); torch.cuda.synchronize()
-ts = []
-for _ in range(7):
-    t0 = time.perf_counter(); t = ops.trim_loss_tables(cloud, panos, trans, groups); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3 / I)
 one = ops.trim_loss_table(cloud, panos[3], trans, groups)
-print("n %d, 8 images, PCL_TRIM_XCD_IMAGES=%s: %.3f ms per image | rows equal the single-image launch: %s" % (
-    n, os.environ.get("PCL_TRIM_XCD_IMAGES"), float(np.median(ts)), bool(torch.equal(torch.nan_to_num(t[3], nan=-1.), torch.nan_to_num(one, nan=-1.)))))
+for tag, order in (("plain order", None), ("row-sorted work list", ops.TrimOrder(cloud, (panos[0].H, panos[0].W, panos[0].fmt), trans, groups))) * 2:
+    t = ops.trim_loss_tables(cloud, panos, trans, groups, order=order); torch.cuda.synchronize()
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter(); t = ops.trim_loss_tables(cloud, panos, trans, groups, order=order); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3 / I)
+    print("n %d, 8 images, %s, PCL_TRIM_XCD_IMAGES=%s: %.3f ms per image | rows equal the single-image launch: %s" % (
+        n, tag, os.environ.get("PCL_TRIM_XCD_IMAGES"), float(np.median(ts)), bool(torch.equal(torch.nan_to_num(t[3], nan=-1.), torch.nan_to_num(one, nan=-1.)))), flush=True)

@@ -19,13 +19,17 @@ for n in [int(a) for a in sys.argv[1:]] or [166_667, 1_000_000]:
     trans = utils.generate_trans_points(X, bench.STANFORD_INIT, device=dev)
     groups, cloud = ops.TrimGroups(rot), ops.Cloud(X, C)
     out = {}
+    # every layout without (plain (chunk, slot) order) and with the row-sorted work list (ops.TrimOrder, round 6), alternating twice
     for fmt in ("u8", "u8p", "u8v", "u8", "u8p", "u8v"):
         pano = ops.Pano(img, fmt=fmt)
-        t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize()
-        ts = []
-        for _ in range(7):
-            t0 = time.perf_counter(); t = ops.trim_loss_table(cloud, pano, trans, groups); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-        out.setdefault(fmt, []).append(float(np.median(ts)))
-        out[fmt + "_table"] = t
+        for tag, order in (("", None), ("+order", ops.TrimOrder(cloud, (pano.H, pano.W, pano.fmt), trans, groups))):
+            t = ops.trim_loss_table(cloud, pano, trans, groups, order=order); torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter(); t = ops.trim_loss_table(cloud, pano, trans, groups, order=order); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+            out.setdefault(fmt + tag, []).append(round(float(np.median(ts)), 3))
+            out[fmt + tag + "_table"] = t
     same = lambda a, b: bool(torch.equal(torch.nan_to_num(out[a + "_table"], nan=-1.0), torch.nan_to_num(out[b + "_table"], nan=-1.0)))
-    print("n %d: u8 %s ms | u8p %s ms | u8v %s ms | tables equal (NaN-aware): u8p %s, u8v %s" % (n, out["u8"], out["u8p"], out["u8v"], same("u8", "u8p"), same("u8", "u8v")))
+    print("n %d: u8 %s +order %s ms | u8p %s +order %s ms | u8v %s +order %s ms | tables equal (NaN-aware): u8p %s, u8v %s, with order: %s" % (
+        n, out["u8"], out["u8+order"], out["u8p"], out["u8p+order"], out["u8v"], out["u8v+order"], same("u8", "u8p"), same("u8", "u8v"),
+        all(same(f, f + "+order") for f in ("u8", "u8p", "u8v"))), flush=True)
