@@ -455,6 +455,11 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
     // runs are requested here, before the tile is initialised (their latency hides behind it); a tile fed by more blocks than that
     // goes through in batches, e0 .. e1 = the entries of one batch.
     __shared__ uint32_t run_first[PCL_RESOLVE_THREADS], run_pre[PCL_RESOLVE_THREADS];
+    // LDS budget: tile 36 992 + histograms 8 192 + slab 12 288 + run tables 8 192 = 65 664 bytes for 1024 threads — above the
+    // 64 KiB of older parts ON PURPOSE: gfx950 has 160 KB per CU and the launch wants exactly two of these workgroups per CU (16 waves each,
+    // 58 VGPRs); the run tables are live together with the slab during the walk, so nothing here can alias.  gfx950 only, like the library.
+    static_assert(sizeof(unsigned long long) * TW * TW + 4 * PCL_HBINS * 4 + 5 * PCL_RESOLVE_THREADS * 4 <= 80 * 1024,
+                  "two resolve workgroups per CU: at most 80 KB of LDS each (gfx950: 160 KB per CU)");
     const uint2* runs = a.runs + ((int64_t)cand * a.nt + t) * a.nb;
     uint2 run0 = make_uint2(0u, 0u);
     if ((int)threadIdx.x < nruns) run0 = runs[threadIdx.x];
