@@ -604,18 +604,6 @@ __global__ void __launch_bounds__(PCL_RESOLVE_THREADS) pcl_tile_resolve_hist_ker
 }
 
 
-// 8 x 8 x 8 colour code of every packed point (0xffff: colour exactly black, never counted): what the resolve kernel needs of a
-// winner — one 2-byte gather instead of three 4-byte gathers from three planes.
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_codes_kernel(const float* __restrict__ cloud, int64_t n, int64_t stride,
-                                                                   uint16_t* __restrict__ codes)
-{
-    const int64_t j = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x;
-    if (j >= n) return;
-    // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
-    const float p0 = -cloud[3 * stride + j] * 255.f, p1 = -cloud[4 * stride + j] * 255.f, p2 = -cloud[5 * stride + j] * 255.f;
-    codes[j] = (p0 == 0.f && p1 == 0.f && p2 == 0.f) ? (uint16_t)0xffffu : (uint16_t)pcl_hist_code(p0, p1, p2);
-}
-
 // Histograms in two steps so that a handful of image blocks still fills the chip: every (block, candidate) is cut into
 // PCL_HSUB pixel ranges, each range is histogrammed in LDS by its own workgroup and its non-empty bins are added to a
 // global counter array (integer atomics: deterministic); a finalise kernel then normalises / intersects.
@@ -663,38 +651,34 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_accum_kernel(const unsigne
         if (hist[i]) atomicAdd(&g[i], hist[i]);
 }
 
-// MODE 0: qhist[blk][512] = hist / hist.sum(), nimg[blk].   MODE 1: inter[cand][blk] = sum min(h / h.sum(), qhist), nproj.
-// (MODE 0: blockIdx.y = query image; MODE 1: blockIdx.y = candidate, intersected with the histograms of image cand / cpi)
-template <int MODE>
-__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_final_kernel(const unsigned int* __restrict__ ghist, float* __restrict__ qhist,
-                                                                   int* __restrict__ nimg, float* __restrict__ inter,
-                                                                   int* __restrict__ nproj, int cpi)
+// inter[cand][blk] = sum min(h / h.sum(), q / q.sum()) (torch.min(h1, h2).sum(), color_utils.py:122-144), nproj[cand][blk] = h.sum(),
+// nimg[image][blk] = q.sum(); h = the candidate's block histogram, q = the block histogram of its query image (image cand / cpi),
+// both as integer counts.  (Rounds 1-5 normalised the query histograms in a launch of their own; the same divisions are made here,
+// per candidate — 512 more per block, one launch less per call.)
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_final_kernel(const unsigned int* __restrict__ ghist_c, const unsigned int* __restrict__ ghist_q,
+                                                                   int* __restrict__ nimg, float* __restrict__ inter, int* __restrict__ nproj, int cpi)
 {
-    __shared__ float red[PCL_BLOCK / PCL_WAVE];
-    const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x;
-    const unsigned int* g = ghist + ((int64_t)cand * nblk + blk) * PCL_HBINS;
-    unsigned int c0 = g[threadIdx.x], c1 = g[threadIdx.x + PCL_BLOCK];
-    float s = pcl_wave_sum((float)(c0 + c1));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __shared__ float red[2][PCL_BLOCK / PCL_WAVE];
+    const int blk = blockIdx.x, cand = blockIdx.y, nblk = gridDim.x, image = cand / cpi;
+    const unsigned int* g = ghist_c + ((int64_t)cand * nblk + blk) * PCL_HBINS;
+    const unsigned int* q = ghist_q + ((int64_t)image * nblk + blk) * PCL_HBINS;
+    const unsigned int c0 = g[threadIdx.x], c1 = g[threadIdx.x + PCL_BLOCK], q0 = q[threadIdx.x], q1 = q[threadIdx.x + PCL_BLOCK];
+    const float s = pcl_wave_sum((float)(c0 + c1)), sq = pcl_wave_sum((float)(q0 + q1));
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = sq; }
     __syncthreads();
-    float total = red[0] + red[1] + red[2] + red[3];
+    const float total = red[0][0] + red[0][1] + red[0][2] + red[0][3], qtotal = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     __syncthreads();
-    if (MODE == 0) {
-        float* q = qhist + ((int64_t)cand * nblk + blk) * PCL_HBINS;                    // (cand = query image here)
-        q[threadIdx.x] = (float)c0 / total;                                             // hist / hist.sum()
-        q[threadIdx.x + PCL_BLOCK] = (float)c1 / total;
-        if (threadIdx.x == 0) nimg[(int64_t)cand * nblk + blk] = (int)total;
-    } else {
-        const float* qh = qhist + ((int64_t)(cand / cpi) * nblk + blk) * PCL_HBINS;
-        float v = fminf((float)c0 / total, qh[threadIdx.x]) + fminf((float)c1 / total, qh[threadIdx.x + PCL_BLOCK]);
-        if (!(total > 0.f)) v = 0.f;
-        v = pcl_wave_sum(v);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            inter[(int64_t)cand * nblk + blk] = red[0] + red[1] + red[2] + red[3];      // torch.min(h1, h2).sum()
-            nproj[(int64_t)cand * nblk + blk] = (int)total;
-        }
+    // hist / hist.sum() on both sides (0 / 0 = NaN for an empty query block: fminf then returns the candidate's value, as torch.min
+    // of the reference's NaN-free path never sees it — such a block is skipped by the slot rule, pcl_hist_score_kernel)
+    float v = fminf((float)c0 / total, (float)q0 / qtotal) + fminf((float)c1 / total, (float)q1 / qtotal);
+    if (!(total > 0.f)) v = 0.f;
+    v = pcl_wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        inter[(int64_t)cand * nblk + blk] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        nproj[(int64_t)cand * nblk + blk] = (int)total;
+        if (cand == image * cpi) nimg[(int64_t)image * nblk + blk] = (int)qtotal;
     }
 }
 
@@ -703,12 +687,32 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_fill_u64b_kernel(unsigned long 
     for (int64_t i = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PCL_BLOCK) p[i] = v;
 }
 
-__global__ void pcl_hist_pose_setup_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int B, PclPoseRec* recs)
+// Everything the stage needs before its first real kernel, in ONE launch (rounds 1-5: a memset, a pose-setup launch, a second memset and
+// the colour-code launch — 20 us of four dependent 5 us launches per image at the shipped shape): the histogram counters and the tiles'
+// statistics zeroed, the candidates' pose records, and the 8 x 8 x 8 colour code of every packed point (tile-binned path: stat / codes
+// non-null).  Grid-stride sections; every word is written by exactly one thread.
+__global__ void __launch_bounds__(PCL_BLOCK) pcl_hist_prepare_kernel(const float* __restrict__ trans, const float* __restrict__ rot, int ncand, PclPoseRec* recs,
+                                                                     unsigned int* __restrict__ ghist, int64_t ghist_words, unsigned long long* __restrict__ stat,
+                                                                     int64_t stat_words, const float* __restrict__ cloud, int64_t n, int64_t stride,
+                                                                     uint16_t* __restrict__ codes)
 {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    float p[6] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2], rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
-    pcl_write_pose_rec(&recs[b], p);
+    const int64_t tid = (int64_t)blockIdx.x * PCL_BLOCK + threadIdx.x, nth = (int64_t)gridDim.x * PCL_BLOCK;
+    if (tid < ncand) {
+        const int b = (int)tid;
+        float p[6] = {trans[3 * b], trans[3 * b + 1], trans[3 * b + 2], rot[3 * b], rot[3 * b + 1], rot[3 * b + 2]};
+        pcl_write_pose_rec(&recs[b], p);
+    }
+    pcl_i4* g4 = (pcl_i4*)ghist;                                   // (the counter area is a whole number of 16-byte words: 512 bins per block)
+    const pcl_i4 z4 = {0, 0, 0, 0};
+    for (int64_t i = tid; i < (ghist_words >> 2); i += nth) g4[i] = z4;
+    if (stat)
+        for (int64_t i = tid; i < stat_words; i += nth) stat[i] = 0ull;
+    if (codes)
+        for (int64_t j = tid; j < n; j += nth) {
+            // image * 255 (utils.py:200); the packed cloud holds -rgb in planes 3..5
+            const float p0 = -cloud[3 * stride + j] * 255.f, p1 = -cloud[4 * stride + j] * 255.f, p2 = -cloud[5 * stride + j] * 255.f;
+            codes[j] = (p0 == 0.f && p1 == 0.f && p2 == 0.f) ? (uint16_t)0xffffu : (uint16_t)pcl_hist_code(p0, p1, p2);
+        }
 }
 
 static size_t hist_align(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -785,32 +789,39 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
     ws += hist_align((size_t)ncand * sizeof(PclPoseRec));
     unsigned long long* zbuf = (unsigned long long*)ws;
     ws += hist_align((size_t)ncand * hist_render_bytes(roomy ? n : 0, H, W));
-    float* qhist = (float*)ws;
     const int nblk = (nsh - 2) * nsw;
-    ws += hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float));
+    ws += hist_align((size_t)nimages * nblk * PCL_HBINS * sizeof(float));       // (rounds 1-5: the normalised query histograms; the layout is kept)
     unsigned int* ghist_q = (unsigned int*)ws;                       // [nimages][nblk][512], then [ncand][nblk][512]
     unsigned int* ghist_c = ghist_q + (size_t)nimages * nblk * PCL_HBINS;
     ws += hist_align((size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int));
     uint8_t* qmask = roomy ? (uint8_t*)ws : nullptr;                 // [nimages][H * W] (tile-binned path only)
     uint16_t* codes = roomy ? (uint16_t*)(ws + hist_align((size_t)nimages * H * W)) : nullptr;
-    hipError_t me = hipMemsetAsync(ghist_q, 0, (size_t)(ncand + nimages) * nblk * PCL_HBINS * sizeof(unsigned int), s);
-    if (me != hipSuccess) return (int)me;
-    hipLaunchKernelGGL(pcl_hist_pose_setup_kernel, dim3((ncand + 255) / 256), dim3(256), 0, s, trans, rot, ncand, recs);
     const int64_t stride = pcl_cloud_stride(n);
+    const int ntx = (W + PCL_TS - 1) / PCL_TS, nty = (H + PCL_TS - 1) / PCL_TS, nt = ntx * nty;
+    const bool binned = roomy && hist_binned_ok(n, H, W);
+    // layout of the tile-binned render area: [ncand] x heads[nt] (16 B), [ncand] x stat[nt] (8 B), [ncand] x runs[nt][nb] (8 B), [ncand] x lists[3][cap]
+    unsigned long long* stat = binned ? (unsigned long long*)((int4*)zbuf + (int64_t)ncand * nt) : nullptr;
+    {
+        const int64_t ghist_words = (int64_t)(ncand + nimages) * nblk * PCL_HBINS, stat_words = binned ? (int64_t)ncand * nt : 0;
+        int64_t work = binned ? n : 0;
+        if (work < (ghist_words >> 2)) work = ghist_words >> 2;
+        if (work < stat_words) work = stat_words;
+        if (work < ncand) work = ncand;
+        const int64_t blocks = (work + PCL_BLOCK - 1) / PCL_BLOCK;
+        hipLaunchKernelGGL(pcl_hist_prepare_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(PCL_BLOCK), 0, s, trans, rot, ncand, recs, ghist_q,
+                           ghist_words, stat, stat_words, cloud, n, stride, binned ? codes : (uint16_t*)nullptr);
+    }
     hipLaunchKernelGGL(pcl_hist_accum_kernel<0>, dim3(nblk * PCL_HSUB, nimages), dim3(PCL_BLOCK), 0, s, (const unsigned long long*)nullptr,
                        cloud, stride, imgs, cpi, H, W, nsh, nsw, ghist_q, qmask);
-    hipLaunchKernelGGL(pcl_hist_final_kernel<0>, dim3(nblk, nimages), dim3(PCL_BLOCK), 0, s, ghist_q, qhist, nimg, inter, nproj, cpi);
     // Tile-binned path when the caller sized the workspace for it (pcl_hist_trim_workspace_bytes_n); a caller that passes the smaller
     // pcl_hist_trim_workspace_bytes gets the z-buffer splat — how the tests compare the two bit for bit.
-    const int ntx = (W + PCL_TS - 1) / PCL_TS, nty = (H + PCL_TS - 1) / PCL_TS, nt = ntx * nty;
     const int64_t cap = 4 * n;
-    if (roomy && hist_binned_ok(n, H, W)) {
+    if (binned) {
         PclBinArgs b;
         b.cloud = cloud; b.n = n; b.stride = stride; b.poses = recs; b.H = H; b.W = W; b.ntx = ntx; b.nt = nt;
-        // layout of the render area: [ncand] x heads[nt] (16 B), [ncand] x stat[nt] (8 B), [ncand] x runs[nt][nb] (8 B), [ncand] x lists[3][cap]
         b.nb = (int)((n + PCL_BIN_PTS - 1) / PCL_BIN_PTS);
         b.heads = (int4*)zbuf;
-        b.stat = (unsigned long long*)(b.heads + (int64_t)ncand * nt);
+        b.stat = stat;
         b.runs = (uint2*)(b.stat + (int64_t)ncand * nt);
         b.lists = (uint32_t*)(b.runs + (int64_t)ncand * nt * b.nb);
         b.cap = cap;
@@ -821,10 +832,7 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         b.fast_margin_y = exact_env ? 0.f : fmaxf(1e-3f, 1.5e-6f * (float)H);
         const int bh = H / nsh, r_hi = (nsh - 1) * bh - 1;
         b.ty_lo = bh >> PCL_TS_SHIFT; b.ty_hi = (r_hi < H - 1 ? r_hi : H - 1) >> PCL_TS_SHIFT;
-        // (a failed memset would leave garbage tile statistics, which become run indices: nothing is launched on top of it)
-        me = hipMemsetAsync(b.stat, 0, (size_t)ncand * nt * sizeof(unsigned long long), s);
-        if (me != hipSuccess) return (int)me;
-        hipLaunchKernelGGL(pcl_hist_codes_kernel, dim3((unsigned)((n + PCL_BLOCK - 1) / PCL_BLOCK)), dim3(PCL_BLOCK), 0, s, cloud, n, stride, codes);
+        // (the tiles' statistics were zeroed and the colour codes written by pcl_hist_prepare_kernel)
         dim3 pgrid((unsigned)b.nb, (unsigned)ncand);
         // pre-dedup pays where pixels hold several points: measured (round 4, two-pass form) at 1M points on 2048 x 1024 (0.5 points per
         // pixel) resolve 613 -> 498, scatter 491 -> 437, count 283 -> 355 us per 64 candidates (-7 % for the stage); at 167k points (0.08
@@ -851,7 +859,8 @@ extern "C" int pcl_hist_trim_scores_images(const float* cloud, int64_t n, const 
         hipLaunchKernelGGL(pcl_hist_accum_kernel<1>, dim3(nblk * PCL_HSUB, ncand), dim3(PCL_BLOCK), 0, s, zbuf, cloud, stride, imgs, cpi, H, W,
                            nsh, nsw, ghist_c, (uint8_t*)nullptr);
     }
-    hipLaunchKernelGGL(pcl_hist_final_kernel<1>, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, ghist_c, qhist, nimg, inter, nproj, cpi);
+    hipLaunchKernelGGL(pcl_hist_final_kernel, dim3(nblk, ncand), dim3(PCL_BLOCK), 0, s, (const unsigned int*)ghist_c, (const unsigned int*)ghist_q, nimg, inter,
+                       nproj, cpi);
     PCL_LAUNCH_CHECK();
     return 0;
 }
