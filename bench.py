@@ -142,6 +142,7 @@ NUM_ITER, LR, PATIENCE, FACTOR, QUANTILE = 100, 0.1, 5, 0.8, 0.05
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_POINT_POSE = 24      # xyz + rgb fp32 read once per pose evaluation
 VALU_PEAK_GINSTR = 1024 * 2.4e9 / 4.0 / 1e9     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2400 MHz
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
 FMT_NAMES = {_lib.PANO_U8: "u8", _lib.PANO_F16: "f16", _lib.PANO_F32: "f32"}
 # the candidate grid of the reference's Stanford configs (75 translations x 24 rotations = 1800 poses on the box room)
 STANFORD_INIT = dict(max_yaw=2 * np.pi, min_yaw=0, max_pitch=2 * np.pi, min_pitch=0, max_roll=2 * np.pi, min_roll=0, z_prior=None,
@@ -555,9 +556,21 @@ def valu_roof(roofs, N, poses_per_launch, avg_launch_ms):
     """The binding roof: wave64 VALU instructions per second of this run against one instruction per SIMD per 4 cycles."""
     wave_instr = roofs["valu_instr_per_point_pose"] * N * poses_per_launch / 64.0
     achieved = wave_instr / (avg_launch_ms * 1e-3) / 1e9
-    return {"achieved": achieved, "peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instr/s", "frac": achieved / VALU_PEAK_GINSTR,
-            "instr_per_point_pose": roofs["valu_instr_per_point_pose"], "wave_instr_per_launch": wave_instr,
-            "busy_frac_profiled": roofs.get("valu_busy_frac"), "source": roofs.get("source"), "source_hash": roofs.get("source_hash")}
+    out = {"achieved": achieved, "peak": VALU_PEAK_GINSTR, "unit": "G wave64 VALU instr/s", "frac": achieved / VALU_PEAK_GINSTR,
+           "instr_per_point_pose": roofs["valu_instr_per_point_pose"], "wave_instr_per_launch": wave_instr,
+           "busy_frac_profiled": roofs.get("valu_busy_frac"), "source": roofs.get("source"), "source_hash": roofs.get("source_hash")}
+    # What `frac` is a fraction OF: the 4-cycle peak is a convention; the kernel's own instruction mix, priced with the measured issue
+    # cost of every opcode class (tools/roof_mix.py: ISA of the loop x tools/micro/valu_rate.hip's table), needs `mix` cycles per
+    # instruction — frac_of_mix_ceiling is the same instruction rate against 1024 SIMDs x 2.4 GHz / mix; fp32_flop_frac the flops of
+    # that mix (fma = 2, packed = twice) against the 157.3 TFLOP/s fp32 vector peak.
+    mix = roofs.get("mix_ceiling_cycles_per_instr")
+    if mix:
+        out["mix_ceiling_cycles_per_instr"] = mix
+        out["frac_of_mix_ceiling"] = out["frac"] * mix / 4.0
+    if roofs.get("fp32_flops_per_point_pose"):
+        out["fp32_flops_per_point_pose"] = roofs["fp32_flops_per_point_pose"]
+        out["fp32_flop_frac"] = roofs["fp32_flops_per_point_pose"] * N * poses_per_launch / (avg_launch_ms * 1e-3) / (FP32_VECTOR_PEAK_TFLOPS * 1e12)
+    return out
 
 
 def run_side(name, ranks, args, lib_hash, pair_ms, timer_stride, scenes, K, ipl, min_seconds=0.6):

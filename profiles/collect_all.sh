@@ -22,4 +22,11 @@ PIPELINE_TAG=depth_mask_cfg2_every_point ROOF_SOURCE=$R/z1_depth_mask_cfg2_strid
 # the driver's own command line (--steps 20 --warmup 5): 4 launch groups of 5 images = 160 poses per launch
 ROOF_KEY=cfg2/poses160/f16 POINT_POSES=160e6 ROOF_SOURCE=$R/g_driver_cfg2_5images ROOF_CMD="bench.py --steps 20 --warmup 5" \
   bash profiles/collect.sh ${R}_g --workload cfg2 --steps 20 --warmup 5 --no-cpu-baseline
+# the trim launch alone, with the counters: plain (chunk, slot) order against the row-sorted work list (round 6), cfg-2 size and the shipped shape
+bash profiles/collect.sh ${R}_t1 --script tools/trim_pmc.py 1000000 plain
+bash profiles/collect.sh ${R}_t2 --script tools/trim_pmc.py 1000000 order
+bash profiles/collect.sh ${R}_t3 --script tools/trim_pmc.py 166667 plain
+bash profiles/collect.sh ${R}_t4 --script tools/trim_pmc.py 166667 order
+# issue cost of the VALU instruction classes, measured in the same collection (tools/roof_mix.py prices the loss kernel's mix with it)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o gpurun_out/valu_rate tools/micro/valu_rate.hip && ./gpurun_out/valu_rate > gpurun_out/valu_rate.txt 2>&1; rm -f gpurun_out/valu_rate
 python3 profiles/merge_roofs.py gpurun_out/prof_${R}_*/summary/roofs.json gpurun_out/prof_${R}_*/summary/pipeline_roofs.json
