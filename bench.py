@@ -12,24 +12,28 @@ every rank refines `steps` images); the only collective is the final all_gather 
     python bench.py --gpus 8 --steps K --warmup W     # starts 8 fresh rank processes itself (self_launch) and relays rank 0's line
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps K --warmup W     # or under torchrun
 
-The JSON line:
+Output.  The LAST line of stdout is ONE compact JSON record below 4 KB (compact_line: what the driver parses — BENCH_r05.parsed was null
+for a 24.5 KB line); the COMPLETE record (the `also` block, per-kernel roofs, notes) goes to the side file --also-json (bench_also.json).
   value / ms_per_step         default mode: 256 // B query images share one launch chain (cfg 4's shape on one GPU)
   single_image {...}          the literal cfg-2 mode: ONE query image per launch chain (B poses per launch)
   roofline {...}              the roof that BINDS the dominant kernel: VALU issue.  The cloud and the panorama are L2 /
                               Infinity-Cache resident (memory-side traffic = 5 % of the HBM peak), so SURVEY.md 8(d)'s
                               algorithmic-bytes figure has saturated (> 1.0) and says nothing about the kernel any more;
-                              it is kept as roofline.algorithmic_hbm.
+                              it is kept as roofline.algorithmic_hbm_frac.
     bound "valu"              achieved = wave64 VALU instructions per second = (instructions per point-pose from the rocprofv3
                               PMC passes of THIS launch shape and THIS library build, profiles/roofs.json) x point-poses per
                               launch / 64 / (this run's average launch time, HIP events minus the measured cost of an empty
-                              event pair); peak = 1024 SIMDs x 2400 MHz / 4 cycles per wave64 instruction.
+                              event pair); peak = 1024 SIMDs x 2400 MHz / 4 cycles per wave64 instruction (a convention);
+                              mix_ceiling_cycles_per_instr / frac_of_mix_ceiling: the same rate against what the kernel's OWN
+                              instruction mix can issue (tools/roof_mix.py: ISA x measured class costs); fp32_flop_frac: its
+                              flops against the 157.3 TFLOP/s vector peak.
                               profiles/roofs.json entries carry pcl_source_hash() of the library they were collected from; if
                               the loaded library differs, valu is null and the line falls back to bound "hbm" (algorithmic).
     roofline.traffic          memory-side bytes per launch from the same PMC passes (2 x FETCH_SIZE + WRITE_SIZE)
-  also {...}                  measured in the same run (N = 1 only, --no-also skips): cfg 3, cfg 5, the reference's shipped
-                              shape (167k points x 6 candidates; 1 and 8 images per launch chain) and the whole per-image
-                              pipeline (make_input + refinement: what the reference's `time (s)` column measures,
-                              localize.py:208,222-223) at cfg-2 size
+  also_brief {...}            one number per side measurement; the side file's `also` {...} holds them whole (N = 1 only, --no-also
+                              skips): cfg 3, cfg 5, the reference's shipped shape (167k points x 6 candidates; 1 and 8 images per
+                              launch chain) and the whole per-image pipeline (make_input + refinement: what the reference's
+                              `time (s)` column measures, localize.py:208,222-223) at cfg-2 size
   cpu_baseline {...}          the C oracle (oracle/pcl_oracle.c compiled with OpenMP: a PORT of the reference's loss +
                               autograd, pinned to the reference by tests/golden) on the host cores
 """

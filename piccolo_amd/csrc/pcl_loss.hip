@@ -391,10 +391,14 @@ void pcl_plan_for_groups(int64_t n, int ngroups, int* nchunks, int* seg_len, int
     // large cloud is then a large piece of the room: at 4M points on 4096 x 2048 (62k points per chunk) the 1800-pose launch took 16.3 ms,
     // with 20k points per chunk 13.3, with 8k 13.0; 10M points: 30.1 / 27.9 (20k) / 28.2 (10k) ms; at 2048 x 1024 the count hardly matters
     // (1M: 3.19 / 3.18 / 3.26 ms at 16k / 8k / 4k points per chunk; 3M: 8.28 / 8.24 / 8.59 at 47k / 20k / 6k) — round 5, tools/trim_u8p.py
-    // with PCL_TRIM_CHUNKS.  Hence: at most 16k points per chunk (the refinement's large-cloud rule in pcl_plan, 8k, is a little worse
-    // here: 10M points 26.9 against 26.2 ms, 3M on 2048 x 1024 7.95 against 7.78).
+    // with PCL_TRIM_CHUNKS.  Hence: at most 16k points per chunk above 2M points (the refinement's large-cloud rule in pcl_plan, 8k, is a
+    // little worse there: 10M points 26.9 against 26.2 ms, 3M on 2048 x 1024 7.95 against 7.78).
+    // Round 6: up to 2M points at most 8k points per chunk.  With the row-sorted work list (pcl_trim_order) a band of the texture is shared by
+    // the chunks that land in it, and a chunk that spans fewer rows spills less into the neighbouring bands: 1M points, 64 -> 128 chunks:
+    // memory-side 9.7 -> 6.6 GB per launch, L2 hit 0.82 -> 0.88, 3.16 -> 3.13 ms (profiles/r06: t2 against the PCL_TRIM_CHUNKS=128 run).
     int auto_chunks = 0;
-    if (chunks_env < 8 && n > (int64_t)64 * 16384) auto_chunks = (int)((n + 16383) / 16384);
+    const int64_t per_chunk = n <= 2000000 ? 8192 : 16384;
+    if (chunks_env < 8 && n > 64 * per_chunk) auto_chunks = (int)((n + per_chunk - 1) / per_chunk);
     if (chunks_env >= 8 || auto_chunks) {
         int64_t steps = (n + PCL_STEP - 1) / PCL_STEP, want = (((chunks_env >= 8 ? chunks_env : auto_chunks) + 7) / 8) * 8;
         if (want > steps) want = ((steps + 7) / 8) * 8;
