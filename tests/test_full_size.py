@@ -239,6 +239,18 @@ def test_full_size_initialisation_stage_vs_oracle(ops, oracle, parity):
     parity("trim_input_loss: mask count over 600 of the 1800 poses (points)", dcount, 40)
     # (a point that is black in fp32 and not in fp64, or vice versa, moves the mean by ~1/n: measured 13 such points, 9e-6)
     parity("trim_input_loss: loss table vs fp64 oracle (600 poses)", rel(table[sub, 0], ref["loss"]), 3e-7 + 2.0 * dcount / n)
+    # the launch the PRODUCT issues at this size: vertical-pair texels and the row-sorted work list (pcl_trim_order, round 6: which block
+    # evaluates which (chunk, slot) item — 128 chunks x 450 slots here — ranked by the panorama row the chunk lands in): the same table
+    # and counts bit for bit as the plain order and as the row-major texels above; the list a permutation in eight equal parts
+    fmt = ops.trim_texels(n, H, W)
+    pano_p = ops.Pano(img, fmt=fmt)
+    assert fmt == "u8v" and ops.trim_order_pays(n, H, W, pano_p.fmt)
+    order = ops.TrimOrder(cloud, (pano_p.H, pano_p.W, pano_p.fmt), trans, groups)
+    hdr = order.data[:16].view(torch.int32).cpu().numpy()
+    items = order.data[256:256 + 4 * int(hdr[1]) * int(hdr[2])].view(torch.int32).cpu().numpy()
+    assert int(hdr[2]) == 450 and int(hdr[1]) % 8 == 0 and int(hdr[3]) == 8 and np.array_equal(np.sort(items), np.arange(len(items)))
+    tl_o, tc_o = ops.trim_loss_table(cloud, pano_p, trans, groups, return_count=True, order=order)
+    assert torch.equal(tl_o, tl) and torch.equal(tc_o, tc)
     t1, r1 = utils.trim_input_loss(img, X, C, trans, rot, K1)
     # the reference's selection on the oracle's table: loss_table.argsort()[:num_input], index // R, index % R (utils.py:500-505);
     # the 300 poses not evaluated beyond rank 300 of the device's table are 1e-5-accurate neighbours of evaluated ones and far
