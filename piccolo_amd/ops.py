@@ -30,14 +30,23 @@ EXPERIMENT = _Experiment()
 F32 = torch.float32
 
 
+_GPU_SEEN = False        # torch.cuda.is_available() answered True once (it is re-asked until then: the product must fail loudly without a GPU)
+
+
 def device():
-    if not torch.cuda.is_available():
-        raise _lib.PiccoloHipError("piccolo_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    global _GPU_SEEN
+    if not _GPU_SEEN:
+        if not torch.cuda.is_available():
+            raise _lib.PiccoloHipError("piccolo_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        _GPU_SEEN = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
 def _dev(t, dtype=F32):
-    """contiguous tensor of `dtype` on the GPU (detached)."""
+    """contiguous tensor of `dtype` on the GPU (detached).  A tensor that already is one is returned as it is (the per-image path of
+    make_input passes ~20 of them per call: the detach / to / contiguous round trip was a third of its host time)."""
+    if torch.is_tensor(t) and t.is_cuda and t.dtype == dtype and not t.requires_grad and t.is_contiguous() and t.device.index == torch.cuda.current_device():
+        return t
     if not torch.is_tensor(t):
         t = torch.as_tensor(t)
     return t.detach().to(device=device(), dtype=dtype).contiguous()
@@ -125,11 +134,13 @@ class Pano:
         if fmt != "f32":
             fn, code = self._PACK[prefer if fmt == "auto" else fmt]
             data = _bytes(lib.pcl_pano_bytes(self.H, self.W, code))
-            flag = torch.zeros(1, dtype=torch.int32, device=img.device)
-            _lib.check(getattr(lib, fn)(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), fn)
             # an image tagged as k/255 by construction (synth.mark_levels: the harness's decoded image files) is not waited for:
-            # reading the flag is a blocking D2H copy per query image in front of a millisecond of work
-            if _known_levels(src) or int(flag.item()) == 0:
+            # reading the flag is a blocking D2H copy per query image in front of a millisecond of work — and a flag nobody reads
+            # need not be zeroed first (a scratch word per device instead of a fill launch per image)
+            known = _known_levels(src)
+            flag = _scratch_flag(img.device) if known else torch.zeros(1, dtype=torch.int32, device=img.device)
+            _lib.check(getattr(lib, fn)(_ptr(img), self.H, self.W, _ptr(data), _ptr(flag), _stream()), fn)
+            if known or int(flag.item()) == 0:
                 self.fmt, self.data = code, data
             elif fmt != "auto":
                 raise ValueError("image is not exactly k/255: cannot use %s texels" % fmt)
@@ -137,6 +148,17 @@ class Pano:
             self.fmt = _lib.PANO_F32
             self.data = _bytes(lib.pcl_pano_bytes(self.H, self.W, _lib.PANO_F32))
             _lib.check(lib.pcl_pano_pack(_ptr(img), self.H, self.W, _ptr(self.data), _stream()), "pcl_pano_pack")
+
+
+_SCRATCH_FLAGS = {}
+
+
+def _scratch_flag(dev):
+    """a device int32 the pack kernels may write their `not_exact` answer to when nobody will read it"""
+    f = _SCRATCH_FLAGS.get(dev)
+    if f is None:
+        f = _SCRATCH_FLAGS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
 
 
 def refine_texels(n, H, W):
