@@ -209,11 +209,11 @@ def trim_order_pays(n, H, W, fmt):
         2048 x 1024: 167k u8p 0.83 -> 0.74 ms, 400k u8p 1.51 -> 1.44, 1M u8v 3.17 -> 3.07 (memory-side 16.4 -> 6.6 GB, L2 hit 0.70 -> 0.88),
                      2M u8v 5.78 -> 5.52; 8 images per launch: 167k 0.747 -> 0.685 per image, 1M 3.10 -> 3.05
         1024 x  512: 100k u8v 0.38 -> 0.38, 500k 1.36 -> 1.35                                      (the texture lives in one L2 either way)
-        4096 x 2048: 3M u8p 10.19 -> 10.48 (u8 11.2 -> 11.8, u8v 13.6 -> 13.1), 10M u8v 28.2 -> 28.1
-    i.e. always up to cfg 2's texture class; for larger panoramas only with vertical-pair texels (a band of a 67 MB texture is several
-    L2s wide whatever the order, and a sparse cloud's launch is bound by texture lines, not by where they come from)."""
+        4096 x 2048: 3M u8p 10.19 -> 10.48 (u8 11.2 -> 11.8, u8v 13.6 -> 13.1), 10M u8v 26.18 -> 26.46 (u8 27.8 -> 28.6)
+    i.e. always up to cfg 2's texture class and never above it: for every layout ops.trim_texels picks on a 4096 x 2048 panorama the list
+    loses 1-3 % (a band of a 67 MB texture is several L2s wide whatever the order; cfg 5's launch stays at round 5's 26.2 ms)."""
     doubled = 8 * (int(H) + 2) * (int(W) + 2)
-    return doubled <= 24_000_000 or int(fmt) == _lib.PANO_U8V
+    return doubled <= 24_000_000
 
 
 def _known_levels(img):

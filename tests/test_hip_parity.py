@@ -314,7 +314,7 @@ def test_trim_loss_table_yaw_shared_vs_generic_kernel_and_oracle(ops, oracle, pa
     small = ops.Cloud(X[:20_000], C[:20_000])
     assert torch.equal(ops.trim_loss_table(small, pano, T(trans), groups, order=order), ops.trim_loss_table(small, pano, T(trans), groups))
     assert ops.trim_order_pays(1_000_000, 1024, 2048, pano.fmt) and ops.trim_order_pays(166_667, 1024, 2048, ops._lib.PANO_U8P)
-    assert ops.trim_order_pays(10_000_000, 2048, 4096, ops._lib.PANO_U8V) and not ops.trim_order_pays(3_000_000, 2048, 4096, ops._lib.PANO_U8P)
+    assert not ops.trim_order_pays(10_000_000, 2048, 4096, ops._lib.PANO_U8V) and not ops.trim_order_pays(3_000_000, 2048, 4096, ops._lib.PANO_U8P)
     assert [ops.trim_texels(n_, 1024, 2048) for n_ in (166_667, 700_000, 1_000_000)] == ["u8p", "u8", "u8v"]
     assert [ops.trim_texels(n_, 2048, 4096) for n_ in (3_000_000, 4_000_000, 10_000_000)] == ["u8p", "u8", "u8v"] and ops.trim_texels(100_000, 512, 1024) == "u8v"
     # passing R for the group count (a caller that never read it back) gives the same table: surplus blocks return at once
