@@ -171,3 +171,35 @@ if rank == 0:
     bad = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=dict(env, FAIL_IF_IPC="0", PCL_HSA_IPC_MODE_LEGACY="0"), cwd=str(tmp_path),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and bad.stdout.strip() == "" and bad.stderr.count("launching 2 ranks") == 1      # forced mode: no retry
+
+
+def test_roofline_mix_ceiling_is_reproducible_from_the_committed_inputs(tmp_path):
+    """`roofline.frac_of_mix_ceiling` / `fp32_flop_frac` must be reproducible by a committed script from committed
+    inputs.  tools/roof_mix.py recompiles csrc/pcl_loss.hip to ISA (hipcc -S: no GPU), prices the loop's VALU opcodes with the class costs
+    of profiles/r06/valu_rate.txt and must give profiles/r06/roof_mix.json again; the entries of profiles/roofs.json carry those figures
+    for the loss-kernel sources they were measured from, and bench.valu_roof turns them into the line's three numbers."""
+    import json
+    import shutil
+    import bench
+    from piccolo_amd import build
+    committed = json.load(open(os.path.join(REPO, "profiles", "r06", "roof_mix.json")))
+    roofs_copy = tmp_path / "roofs.json"
+    shutil.copy(os.path.join(REPO, "profiles", "roofs.json"), roofs_copy)
+    out = tmp_path / "roof_mix.json"
+    subprocess.check_call([sys.executable, os.path.join(REPO, "tools", "roof_mix.py"), "--roofs", str(roofs_copy), "--out", str(out)], cwd=REPO)
+    again = json.load(open(out))
+    assert set(again["instances"]) == {"f16", "u8", "f32"}
+    for k, inst in again["instances"].items():
+        assert inst["valu_instructions_in_loop"] > 500 and 4.0 < inst["mix_ceiling_cycles_per_instr"] < 5.0 and 1.5 < inst["fp32_flops_per_instr"] < 2.0
+        assert not [o for o in inst["priced_by_class_default"] if not o.startswith("v_mov")]          # every other opcode has a measured class
+    if committed["loss_kernel_source_hash"] == build.loss_kernel_source_hash():                        # (same kernel sources: the same numbers)
+        for k in committed["instances"]:
+            assert abs(again["instances"][k]["mix_ceiling_cycles_per_instr"] - committed["instances"][k]["mix_ceiling_cycles_per_instr"]) < 1e-9
+            assert again["instances"][k]["valu_instructions_in_loop"] == committed["instances"][k]["valu_instructions_in_loop"]
+    roofs = json.load(open(os.path.join(REPO, "profiles", "roofs.json")))
+    e = roofs["cfg2/poses160/f16"]
+    if e["source_hash"] == committed["loss_kernel_source_hash"]:
+        assert abs(e["mix_ceiling_cycles_per_instr"] - committed["instances"]["f16"]["mix_ceiling_cycles_per_instr"]) < 1e-9
+    v = bench.valu_roof(e, 1_000_000, 160, 0.45)
+    assert abs(v["frac_of_mix_ceiling"] - v["frac"] * e["mix_ceiling_cycles_per_instr"] / 4.0) < 1e-12 and 0.9 < v["frac_of_mix_ceiling"] < 1.0
+    assert abs(v["fp32_flop_frac"] - e["fp32_flops_per_point_pose"] * 160e6 / 0.45e-3 / 157.3e12) < 1e-12 and 0.3 < v["fp32_flop_frac"] < 0.5
