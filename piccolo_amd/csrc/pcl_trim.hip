@@ -493,7 +493,7 @@ static size_t trim_align(size_t v) { return (v + 255) & ~(size_t)255; }
 // lands in does not depend on the yaw (the four yaws of a slot share theta) and is known from the chunk's centroid: rank the items by
 // that row, cut the ranking into `bands` equal parts (a multiple of 8), give every XCD a contiguous eighth of them and walk each band
 // chunk by chunk.  An XCD's L2 then holds one band of the texture (2 MB of 17) for ALL the poses: 16.4 -> 6.6 GB per launch, L2 hit
-// 0.70 -> 0.88 (tools/trim_order_proto.py, profiles/r06).  The list depends on the cloud, the candidate grid and the texture's size —
+// 0.70 -> 0.88 (profiles/r06: t1 / t2, tools/trim_pmc.py; the host-made prototype: profiles/EXPERIMENTS.md section 10).  The list depends on the cloud, the candidate grid and the texture's size —
 // not on the query image: it is built ONCE per room (pcl_trim_order; two radix sorts of chunks x slots keys) and handed to every
 // image's launch.  The partial sum of every (chunk, slot) is what it was: tables are bit-identical with and without the list.
 struct PclTrimOrderHdr {
@@ -559,17 +559,22 @@ __global__ void __launch_bounds__(PCL_BLOCK) pcl_trim_bandkey_kernel(PclTrimSort
     key[pos] = (unsigned int)(band * a.nchunks + (int)(ranked[pos] / (unsigned int)a.nslots));
 }
 
-__global__ void pcl_trim_order_hdr_kernel(PclTrimOrderHdr* h, int nchunks, int nslots, int bands)
+// the header is what makes a list VALID for the trim kernel: cleared before the list is touched, written after the last sort (a call that
+// fails half way leaves a blob the kernel ignores, never a valid header over a half-written list)
+__global__ void pcl_trim_order_hdr_kernel(PclTrimOrderHdr* h, int magic, int nchunks, int nslots, int bands)
 {
-    if (threadIdx.x == 0) { h->magic = PCL_TRIM_ORDER_MAGIC; h->nchunks = nchunks; h->nslots = nslots; h->bands = bands; }
+    if (threadIdx.x == 0) { h->magic = magic; h->nchunks = nchunks; h->nslots = nslots; h->bands = bands; }
 }
 
+// temporary storage of the two sorts (16-bit row keys, 32-bit (band, chunk) keys): the larger of the two queries
 static size_t trim_sort_temp_bytes(size_t M)
 {
-    size_t bytes = 0;
+    size_t b16 = 0, b32 = 0;
     (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned int*, unsigned int*, const unsigned int*, unsigned int*>(
-        nullptr, bytes, nullptr, nullptr, nullptr, nullptr, M, 0, 32, nullptr, false);
-    return bytes;
+        nullptr, b16, nullptr, nullptr, nullptr, nullptr, M, 0, 16, nullptr, false);
+    (void)rocprim::radix_sort_pairs<rocprim::default_config, const unsigned int*, unsigned int*, const unsigned int*, unsigned int*>(
+        nullptr, b32, nullptr, nullptr, nullptr, nullptr, M, 0, 32, nullptr, false);
+    return b16 > b32 ? b16 : b32;
 }
 
 // bands: a multiple of 8, sized so that one band of the texture is about 2 MB (an XCD's L2 is 4 MB and also holds the cloud chunks)
@@ -642,6 +647,7 @@ extern "C" int pcl_trim_order(const float* cloud, int64_t n, int pano_format, in
     size_t temp_bytes = trim_sort_temp_bytes(M);
     PclTrimOrderHdr* oh = (PclTrimOrderHdr*)order;
     unsigned int* list = (unsigned int*)(oh + 1);
+    hipLaunchKernelGGL(pcl_trim_order_hdr_kernel, dim3(1), dim3(64), 0, s, oh, 0, 0, 0, 0);
     hipLaunchKernelGGL(pcl_trim_pose_setup_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, trans, rot, K, hdr, grs, ngroups, recs);
     hipLaunchKernelGGL(pcl_trim_centroid_kernel, dim3(so.nchunks), dim3(PCL_BLOCK), 0, s, so);
     const unsigned nb = (unsigned)((M + PCL_BLOCK - 1) / PCL_BLOCK);
@@ -656,7 +662,7 @@ extern "C" int pcl_trim_order(const float* cloud, int64_t n, int pano_format, in
     // (band, chunk)-major, stable: inside a cell the row ranking survives
     e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned int*)k0, k1, (const unsigned int*)v0, list, M, 0, 32, s, false);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(pcl_trim_order_hdr_kernel, dim3(1), dim3(64), 0, s, oh, so.nchunks, nslots, so.bands);
+    hipLaunchKernelGGL(pcl_trim_order_hdr_kernel, dim3(1), dim3(64), 0, s, oh, PCL_TRIM_ORDER_MAGIC, so.nchunks, nslots, so.bands);
     PCL_LAUNCH_CHECK();
     return 0;
 }
