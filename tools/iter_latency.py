@@ -34,14 +34,15 @@ if spread:
     if spread == 3:        # pairs share the translation, rotations differ
         for k in range(0, B - 1, 2):
             tr[k + 1] = tr[k]
-cloud, pano, box = ops.Cloud(X, C), ops.Pano(img), ops.quantile_box(X, 0.05)
+FMT = ops.EXPERIMENT.pano_fmt or ops.refine_texels(N, H, W)      # the product's texel format for this cloud / panorama unless PCL_PANO_FMT forces one
+cloud, pano, box = ops.Cloud(X, C), ops.Pano(img, fmt=FMT), ops.quantile_box(X, 0.05)
 gd = ops.GradientDescent(cloud, pano, torch.from_numpy(tr).to(dev), torch.from_numpy(ro).to(dev), box, lr=0.1, patience=5, factor=0.8, batch_mode=True)
 NIMG = int(os.environ.get("ITER_IMAGES", "1"))           # ITER_IMAGES=8: the B candidates split over 8 query images (own panoramas)
 if NIMG > 1:
     panos = []
     for k in range(NIMG):
         tg, yg = synth.gt_pose(100 + k)
-        panos.append(ops.Pano(synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(tg), torch.from_numpy(yg)), C, (H, W)))))
+        panos.append(ops.Pano(synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, torch.from_numpy(tg), torch.from_numpy(yg)), C, (H, W))), fmt=FMT))
     gd.set_pano_groups(panos)
 gd.run_graph(100); torch.cuda.synchronize()
 ts = []
