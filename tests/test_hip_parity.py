@@ -1201,3 +1201,48 @@ def test_cloud_repack_reuses_the_morton_order(ops):
     assert torch.equal(b.order, fresh.order) and torch.equal(b.data, fresh.data)
     with pytest.raises(ValueError):
         ops.Cloud(X, C2, order=a.order[:-1])
+
+
+@pytest.mark.gpu
+def test_trim_work_list_is_scheduling_only_on_random_shapes(ops):
+    """pcl_trim_order on shapes nobody tuned: random cloud sizes (incl. fewer steps than chunks), translation counts, rotation tables
+    (quarter-turn grid, yaw-only, arbitrary: classes of one yaw), panorama sizes, texel layouts and images per launch.  With the list
+    every table and count equals the plain order's bit for bit; the list is a permutation of the items whose eight XCD parts hold
+    ascending bands (first key of the second sort); a second call into the same blob leaves a valid list."""
+    from piccolo_amd import synth, utils
+    from test_hip_harness import STANFORD
+    rng = np.random.default_rng(11)
+    stanford = utils.generate_rot_points(dict(STANFORD), device=torch.device("cuda")).cpu().numpy()
+    for case in range(7):
+        n = int(rng.choice([700, 5_000, 33_333, 120_000, 400_000]))
+        H = int(rng.choice([64, 96, 200])); W = 2 * H
+        K = int(rng.integers(1, 40))
+        kind = case % 3
+        rot = stanford if kind == 0 else np.stack([np.arange(8) * np.pi / 4, np.zeros(8), np.zeros(8)], 1).astype(np.float32) if kind == 1 \
+            else rng.uniform(-3.0, 3.0, size=(int(rng.integers(1, 9)), 3)).astype(np.float32)
+        fmt = ["u8", "u8p", "u8v", "f16"][case % 4]
+        nimg = int(rng.choice([1, 2, 8, 9]))
+        xyz, rgb = synth.box_room(n, 40 + case)
+        X, C = T(xyz), T(rgb)
+        cloud = ops.Cloud(X, C)
+        panos = []
+        for i in range(nimg):
+            t_gt, ypr_gt = synth.gt_pose(60 + case * 10 + i)
+            img = synth.quantise_like_image_file(ops.make_pano(ops.transform_cloud(X, T(t_gt), T(ypr_gt)), C, (H, W)))
+            panos.append(ops.Pano(img, fmt=fmt))
+        trans = T(rng.uniform(-2.0, 2.0, size=(K, 3)).astype(np.float32))
+        groups = ops.TrimGroups(T(rot))
+        order = ops.TrimOrder(cloud, (H, W, panos[0].fmt), trans, groups)
+        for _ in range(2):                                        # (built twice into fresh blobs, and compared both times)
+            plain, cplain = ops.trim_loss_tables(cloud, panos, trans, groups, return_count=True)
+            listed, clisted = ops.trim_loss_tables(cloud, panos, trans, groups, return_count=True, order=order)
+            assert torch.equal(torch.nan_to_num(plain, nan=-1.0), torch.nan_to_num(listed, nan=-1.0)) and torch.equal(cplain, clisted), (case, n, K, fmt, nimg)
+            order = ops.TrimOrder(cloud, (H, W, panos[0].fmt), trans, groups)
+        hdr = order.data[:16].view(torch.int32).cpu().numpy()
+        nchunks, nslots, bands = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        items = order.data[256:256 + 4 * nchunks * nslots].view(torch.int32).cpu().numpy()
+        assert hdr[0] == 0x524f5450 and nslots == groups.ngroups * K and bands % 8 == 0
+        assert np.array_equal(np.sort(items), np.arange(nchunks * nslots)), (case, "not a permutation")
+        # inside one band the chunks ascend (chunk-major): check the first band
+        first_band = items[: max(1, (nchunks * nslots) // bands)] // nslots
+        assert np.all(np.diff(first_band) >= 0), case
